@@ -1,0 +1,234 @@
+/*
+ * seismic_hip.h — C ABI of the MI355X-native Seismic search hot path.
+ *
+ * This is the drop-in boundary. The reference (TusKANNy/seismic, Rust) has no
+ * C ABI of its own; its narrowest seam for this path is the Rust method
+ *
+ *   InvertedIndexBase::<S>::search(&self, query: SparseVectorView<C, f32>,
+ *       k, query_cut, heap_factor, n_knn, first_sorted) -> Vec<ScoredVectorDotProduct>
+ *   (reference: src/inverted_index.rs:153-234)
+ *
+ * wrapped by SeismicIndex::search_raw/search (src/inverted_index_wrapper.rs:218-284)
+ * and by the PyO3 classes (src/pylib/mod.rs:504-533, 587-655, 1046-1076, 1111-1146).
+ * Every entry point below names the reference item it replaces. INTEGRATION.md
+ * shows the `extern "C"` block a maintainer of the reference would add to bind it.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every buffer it passes in
+ *     or receives results in; the library keeps no pointer past the call
+ *     (sgpu_index_create COPIES the descriptor's arrays).
+ *   - every function returns an sgpu_status; nothing aborts or throws across
+ *     the boundary (the reference panics instead: src/inverted_index.rs:172-175,
+ *     src/utils.rs:23).
+ *   - results are best-first; fewer than k results is not an error
+ *     (src/bin/perf_inverted_index.rs:201-206); out_n[q] gives the valid count.
+ *   - the search entry points run on the GPU only. There is no CPU fallback:
+ *     without a usable HIP device they return SGPU_EDEVICE.
+ */
+#ifndef SEISMIC_HIP_H
+#define SEISMIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sgpu_status {
+  SGPU_OK = 0,
+  SGPU_EINVAL = 1,   /* bad argument: k==0, unsorted/duplicate query components,
+                        component >= dim, n_knn != 0, inconsistent descriptor */
+  SGPU_EDEVICE = 2,  /* HIP failure / no device / index not uploaded */
+  SGPU_ENOMEM = 3,   /* host or device allocation failed */
+  SGPU_EIO = 4,      /* file could not be read / written / parsed */
+  SGPU_ELIMIT = 5    /* a documented capacity limit of the kernel was exceeded */
+} sgpu_status;
+
+/* ------------------------------------------------------------------------
+ * Index descriptor: the searchable state of the reference's
+ * InvertedIndexBase<S> (src/inverted_index.rs:39-52) as flat host SoA arrays.
+ *
+ *   forward index  (reference: vectorium SparseDataset; call sites
+ *                   src/posting_list.rs:203,210, src/inverted_index.rs:231)
+ *     doc d = components fwd_comps[fwd_offsets[d] .. fwd_offsets[d+1]) (ascending)
+ *             values     fwd_vals [same range], IEEE binary16 bit patterns
+ *   posting lists  (reference: PostingList<C>, src/posting_list.rs:68-73)
+ *     list c (one per component id) owns blocks
+ *             [list_block_start[c], list_block_start[c+1])      (global block ids)
+ *     block b owns postings [block_post_start[b], block_post_start[b+1])
+ *     posting p refers to document post_doc[p]  (the reference packs
+ *             (offset<<16)|len, src/posting_list.rs:32-60; offset/len are
+ *             recovered here from fwd_offsets)
+ *   quantized summaries (reference: QuantizedSummary<C>, src/quantized_summary.rs:15-24)
+ *     blk_min[b], blk_quant[b]: dequantisation of block b's summary
+ *     list c owns summary rows [list_row_start[c], list_row_start[c+1]);
+ *     row r: component row_comp[r] (ascending within a list), entries
+ *            [row_ptr[r], row_ptr[r+1]): sum_bid[e] = block id LOCAL to the list
+ *            (ascending within a row), sum_code[e] = u8 code.
+ *     (the reference stores the same CSR with Elias-Fano offsets and a packed
+ *      BitField of summary ids; the codecs carry no arithmetic.)
+ * ---------------------------------------------------------------------- */
+typedef struct sgpu_index_desc {
+  uint32_t comp_width;            /* 2 (SeismicIndex, u16) or 4 (SeismicIndexLV, u32) */
+  uint32_t reserved;
+  uint64_t n_docs;
+  uint64_t dim;                   /* number of components == number of posting lists */
+  uint64_t nnz;                   /* fwd_offsets[n_docs] */
+  uint64_t n_blocks;              /* list_block_start[dim] */
+  uint64_t n_postings;            /* block_post_start[n_blocks] */
+  uint64_t n_rows;                /* list_row_start[dim] */
+  uint64_t n_entries;             /* row_ptr[n_rows] */
+  const uint64_t* fwd_offsets;    /* n_docs + 1 */
+  const void* fwd_comps;          /* nnz x comp_width bytes */
+  const uint16_t* fwd_vals;       /* nnz, binary16 bits */
+  const uint64_t* list_block_start; /* dim + 1 */
+  const uint64_t* block_post_start; /* n_blocks + 1 */
+  const uint32_t* post_doc;       /* n_postings */
+  const float* blk_min;           /* n_blocks */
+  const float* blk_quant;         /* n_blocks */
+  const uint64_t* list_row_start; /* dim + 1 */
+  const void* row_comp;           /* n_rows x comp_width bytes */
+  const uint64_t* row_ptr;        /* n_rows + 1 */
+  const uint16_t* sum_bid;        /* n_entries */
+  const uint8_t* sum_code;        /* n_entries */
+} sgpu_index_desc;
+
+/* Build-time configuration; mirrors Configuration (src/configurations.rs:15-129)
+ * restricted to the path the Python API exposes (src/pylib/mod.rs:329-369):
+ * GlobalThreshold pruning, RandomKmeansInvertedIndexApprox blocking,
+ * EnergyPreserving summaries. Defaults = the reference's Python defaults. */
+typedef struct sgpu_build_config {
+  uint64_t n_postings;        /* 3500 */
+  float centroid_fraction;    /* 0.1  */
+  uint32_t min_cluster_size;  /* 2    */
+  float summary_energy;       /* 0.4  */
+  float max_fraction;         /* 1.5  */
+  uint32_t doc_cut;           /* 15   */
+  uint32_t num_threads;       /* 0 = all host cores */
+} sgpu_build_config;
+
+/* Query-time knobs of InvertedIndexBase::search (src/inverted_index.rs:153-161). */
+typedef struct sgpu_search_params {
+  uint32_t k;            /* > 0 */
+  uint32_t query_cut;    /* number of heaviest query components whose lists are walked */
+  float heap_factor;     /* skip block iff heap full && dot < heap_factor * kth_best */
+  uint32_t n_knn;        /* must be 0: no kNN graph on this path (src/inverted_index.rs:215) */
+  int32_t first_sorted;  /* !=0: first list visited by descending summary dot
+                            (PostingList::sort_and_search, src/posting_list.rs:149-185) */
+} sgpu_search_params;
+
+typedef struct sgpu_index sgpu_index;     /* host + device state of one index */
+typedef struct sgpu_batch sgpu_batch;     /* a device-resident query batch + result slab */
+
+/* Per-launch measurements of the search kernel (HIP events on the library's stream). */
+typedef struct sgpu_launch_stats {
+  float kernel_ms;         /* duration of the last search kernel launch */
+  uint32_t n_queries;
+  uint32_t grid;           /* workgroups launched */
+  uint32_t block;          /* threads per workgroup */
+  uint32_t lds_bytes;      /* dynamic LDS per workgroup */
+} sgpu_launch_stats;
+
+/* ---- library ---------------------------------------------------------- */
+/* Thread-local message for the last non-OK status returned on this thread. */
+const char* sgpu_last_error(void);
+/* ABI version of this header (bumped on any layout change). */
+uint32_t sgpu_abi_version(void);
+/* Number of visible HIP devices; SGPU_EDEVICE (and *n = 0) when none. */
+sgpu_status sgpu_device_count(int32_t* n);
+
+/* ---- index life cycle -------------------------------------------------- */
+/* Replaces: holding an InvertedIndexBase<S> (src/inverted_index.rs:39-52).
+ * Validates the descriptor, copies it, derives the HBM layout. */
+sgpu_status sgpu_index_create(const sgpu_index_desc* desc, sgpu_index** out);
+/* Replaces: InvertedIndexBase::build (src/inverted_index.rs:603-686) for the
+ * Python-exposed configuration. CPU-side, offline. Input = a sparse dataset in
+ * CSR form, values already f32 (they are rounded to binary16 as
+ * from_f32_saturating does, src/json_utils.rs:64). comps are comp_width bytes each. */
+sgpu_status sgpu_index_build(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
+                             const uint64_t* offsets, const void* comps,
+                             const float* vals, const sgpu_build_config* cfg,
+                             sgpu_index** out);
+/* View of the index's canonical host arrays; valid until sgpu_index_destroy. */
+sgpu_status sgpu_index_get_desc(const sgpu_index* idx, sgpu_index_desc* out);
+/* Replaces: IndexSerializer::save_index / load_index (src/pylib/mod.rs:186-221).
+ * Own flat SoA file format (the reference's wire format lives in un-vendored vectorium). */
+sgpu_status sgpu_index_save(const sgpu_index* idx, const char* path);
+sgpu_status sgpu_index_load(const char* path, sgpu_index** out);
+/* Copies the index into the HBM of HIP device `device` (one device per index;
+ * multi-GPU = one process/index replica per GPU). */
+sgpu_status sgpu_index_upload(sgpu_index* idx, int32_t device);
+/* Bytes resident in HBM after upload (0 before). */
+uint64_t sgpu_index_device_bytes(const sgpu_index* idx);
+void sgpu_index_destroy(sgpu_index* idx);
+
+/* ---- search ------------------------------------------------------------ */
+/* Replaces: InvertedIndexBase::search (src/inverted_index.rs:153-234) /
+ * SeismicIndexRaw.search (src/pylib/mod.rs:1046-1076).
+ * comps ascending, strictly increasing, < dim (u32 regardless of comp_width).
+ * out_scores/out_doc_ids have room for params->k entries. */
+sgpu_status sgpu_search(sgpu_index* idx, const uint32_t* comps, const float* vals,
+                        uint32_t nnz, const sgpu_search_params* params,
+                        float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n);
+/* Replaces: SeismicIndexRaw.batch_search (src/pylib/mod.rs:1111-1146) and the
+ * per-query loop of SeismicIndex.batch_search (src/pylib/mod.rs:629-652).
+ * Queries in CSR form: query q = [q_off[q], q_off[q+1]). Results in input
+ * order: out_scores/out_doc_ids are nq x k (row q padded past out_n[q]). */
+sgpu_status sgpu_batch_search(sgpu_index* idx, const uint64_t* q_off,
+                              const uint32_t* comps, const float* vals, uint32_t nq,
+                              const sgpu_search_params* params, float* out_scores,
+                              uint64_t* out_doc_ids, uint32_t* out_n);
+
+/* Device-resident variant (what bench.py times: inputs already in HBM when the
+ * timed region starts; results stay in HBM until fetched). */
+sgpu_status sgpu_batch_create(sgpu_index* idx, const uint64_t* q_off,
+                              const uint32_t* comps, const float* vals, uint32_t nq,
+                              uint32_t k_max, sgpu_batch** out);
+/* Enqueues one search pass over the batch on the library's stream. With
+ * sync != 0 waits for it and fills *stats (may be NULL). */
+sgpu_status sgpu_batch_run(sgpu_index* idx, sgpu_batch* batch,
+                           const sgpu_search_params* params, int32_t sync,
+                           sgpu_launch_stats* stats);
+/* Blocks until all enqueued passes are done. */
+sgpu_status sgpu_batch_sync(sgpu_index* idx);
+sgpu_status sgpu_batch_fetch(sgpu_index* idx, sgpu_batch* batch, uint32_t k,
+                             float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n);
+void sgpu_batch_destroy(sgpu_batch* batch);
+
+/* Hot loop A in isolation — replaces QuantizedSummary::distances
+ * (src/quantized_summary.rs:64-160) for posting list `list`: writes one f32
+ * per block of that list (out_dots has room for n_blocks(list) entries). */
+sgpu_status sgpu_summary_distances(sgpu_index* idx, uint32_t list, const uint32_t* comps,
+                                   const float* vals, uint32_t nnz, float* out_dots,
+                                   uint32_t* out_n_blocks);
+
+/* ---- host-side helpers around the path (CPU, not on the hot path) ------ */
+/* Replaces: SeismicDataset.search (exact, vectorium FlatIndex;
+ * src/inverted_index_wrapper.rs:721-742) — ground truth for recall@k.
+ * Brute force over the forward index of `idx`, multi-threaded on the host. */
+sgpu_status sgpu_exact_search(const sgpu_index* idx, const uint64_t* q_off,
+                              const uint32_t* comps, const float* vals, uint32_t nq,
+                              uint32_t k, uint32_t num_threads, float* out_scores,
+                              uint64_t* out_doc_ids, uint32_t* out_n);
+/* Deterministic SPLADE-shaped synthetic data: writes a
+ * CSR dataset into caller-provided buffers. Call with comps==NULL to size:
+ * *out_nnz receives the number of entries. kind: 0 = documents, 1 = queries
+ * (queries draw 60% of their tokens from a random source document of `docs_*`). */
+typedef struct sgpu_synth_spec {
+  uint64_t n_vecs;
+  uint64_t dim;
+  uint64_t seed;
+  uint32_t kind;        /* 0 docs, 1 queries */
+  uint32_t reserved;
+} sgpu_synth_spec;
+sgpu_status sgpu_synth_generate(const sgpu_synth_spec* spec,
+                                const uint64_t* docs_offsets, const uint32_t* docs_comps,
+                                const float* docs_vals, uint64_t n_docs,
+                                uint64_t* out_offsets, uint32_t* out_comps, float* out_vals,
+                                uint64_t* out_nnz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEISMIC_HIP_H */

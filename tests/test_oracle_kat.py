@@ -1,0 +1,169 @@
+"""Pins the CPU oracle to the reference's OWN known-answer tests for this path.
+
+  - test_empty_vectors           reference src/inverted_index.rs:716-772
+  - test_distances_iter          reference src/quantized_summary.rs:519-598
+  - docs example                 reference docs/RustUsage.md:138-157
+Inputs/expected values are restated as data (see tests/golden/README.md).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from seismic_amd._abi import BuildConfig
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _build(vectors, dim, comp_width=2, **cfg):
+    off, comps, vals = orc.csr(vectors)
+    return orc.OracleIndex(comp_width, dim, off, comps, vals, BuildConfig.defaults(**cfg))
+
+
+def test_empty_vectors_kat():
+    g = json.load(open(os.path.join(GOLD, "kat_empty_vectors.json")))
+    ix = _build([(d["components"], d["values"]) for d in g["docs"]], g["dim"])
+    assert ix.desc.n_docs == 4 and ix.desc.dim == 5 and ix.desc.nnz == 7
+    q = g["query"]
+    for order in (orc.ORDER_LANES16, orc.ORDER_SEQ):
+        sc, ids = orc.search(ix.desc, q["components"], q["values"], q["k"], q["query_cut"],
+                             q["heap_factor"], q["first_sorted"], order)
+        assert ids.tolist() == g["expected_ids"]          # [3, 0]: empty docs never retrieved
+        assert sc.tolist() == g["expected_scores"]        # 30, 7 (exact small integers)
+
+
+def test_rust_usage_doc_example():
+    g = json.load(open(os.path.join(GOLD, "kat_rust_usage.json")))
+    ix = _build([(d["components"], d["values"]) for d in g["docs"]], g["dim"])
+    q = g["query"]
+    sc, ids = orc.search(ix.desc, q["components"], q["values"], q["k"], q["query_cut"],
+                         q["heap_factor"], False)
+    assert ids.tolist() == g["expected_ids"] and sc.tolist() == g["expected_scores"]
+
+
+def test_convert_dataset_preserves_postings_property():
+    # reference src/inverted_index.rs:774-807: every posting doc id < len, postings non-empty
+    ix = _build([([0, 2], [1.0, 2.0]), ([1, 3], [3.0, 4.0])], 4)
+    a = orc.desc_arrays(ix.desc)
+    assert len(a["post_doc"]) > 0 and (a["post_doc"] < 2).all()
+
+
+def _merge_dot(qc, qv, dc, dv):
+    i = j = 0
+    r = np.float32(0)
+    while i < len(qc) and j < len(dc):
+        if qc[i] == dc[j]:
+            r = np.float32(r + np.float32(qv[i]) * np.float32(dv[j]))
+            i += 1
+            j += 1
+        elif qc[i] < dc[j]:
+            i += 1
+        else:
+            j += 1
+    return r
+
+
+@pytest.mark.parametrize("comp_width", [4])
+def test_distances_iter_property(comp_width):
+    """All-ones vectors => quantisation is lossless (min==max -> quant 0 -> NaN -> code 0
+    -> dequant == min), so distances() must equal the exact merge dot within 1e-5."""
+    rng = np.random.default_rng(142)
+    n_vecs = int(rng.integers(50, 101))
+    dim = int(rng.integers(100_000, 140_001))
+    vecs = []
+    for _ in range(n_vecs):
+        nnz = int(rng.integers(300, 501))
+        c = np.sort(rng.choice(dim, nnz, replace=False)).astype(np.uint32)
+        vecs.append((c, np.ones(nnz, np.float32)))
+    # Put all vectors into ONE posting block each: build a one-list "index" by hand is
+    # overkill; instead check the QuantizedSummary arithmetic through a synthetic desc:
+    import ctypes as C
+    from seismic_amd._abi import IndexDesc
+    # summary dataset == the vectors themselves; list 0 owns all n_vecs blocks
+    mins, quants, rows = [], [], {}
+    for b, (c, v) in enumerate(vecs):
+        mn, qt, codes = orc.quantize(v)
+        assert qt == 0.0 and (codes == 0).all() and mn == 1.0
+        mins.append(mn)
+        quants.append(qt)
+        for ci, code in zip(c, codes):
+            rows.setdefault(int(ci), []).append((b, int(code)))
+    row_comp = np.array(sorted(rows), np.uint32)
+    row_ptr = np.zeros(len(row_comp) + 1, np.uint64)
+    bid, code = [], []
+    for i, c in enumerate(row_comp):
+        for b, cd in rows[int(c)]:
+            bid.append(b)
+            code.append(cd)
+        row_ptr[i + 1] = len(bid)
+    bid = np.array(bid, np.uint16)
+    code = np.array(code, np.uint8)
+    mins = np.array(mins, np.float32)
+    quants = np.array(quants, np.float32)
+    lbs = np.zeros(dim + 1, np.uint64)
+    lbs[1:] = n_vecs
+    lrs = np.zeros(dim + 1, np.uint64)
+    lrs[1:] = len(row_comp)
+    bps = np.zeros(n_vecs + 1, np.uint64)
+    fo = np.zeros(1, np.uint64)
+    d = IndexDesc(comp_width=4, n_docs=0, dim=dim, nnz=0, n_blocks=n_vecs, n_postings=0,
+                  n_rows=len(row_comp), n_entries=len(bid))
+    keep = [lbs, lrs, bps, fo, row_comp, row_ptr, bid, code, mins, quants]
+    d.fwd_offsets = fo.ctypes.data_as(type(d.fwd_offsets))
+    d.list_block_start = lbs.ctypes.data_as(type(d.list_block_start))
+    d.block_post_start = bps.ctypes.data_as(type(d.block_post_start))
+    d.blk_min = mins.ctypes.data_as(type(d.blk_min))
+    d.blk_quant = quants.ctypes.data_as(type(d.blk_quant))
+    d.list_row_start = lrs.ctypes.data_as(type(d.list_row_start))
+    d.row_comp = row_comp.ctypes.data_as(C.c_void_p)
+    d.row_ptr = row_ptr.ctypes.data_as(type(d.row_ptr))
+    d.sum_bid = bid.ctypes.data_as(type(d.sum_bid))
+    d.sum_code = code.ctypes.data_as(type(d.sum_code))
+    queries = []
+    for _ in range(100):
+        nnz = int(rng.integers(300, 501))
+        c = np.sort(rng.choice(dim, nnz, replace=False)).astype(np.uint32)
+        queries.append((c, rng.random(nnz, dtype=np.float32)))
+    queries += vecs
+    for qc, qv in queries:
+        got = orc.summary_distances(d, 0, qc, qv)
+        assert len(got) == n_vecs
+        exp = np.array([_merge_dot(qc, qv, c, v) for c, v in vecs], np.float32)
+        assert np.abs(got - exp).max() < 1e-5
+    del keep
+
+
+def test_quantize_traps():
+    # reference src/utils.rs:68-90 — half-away-from-zero rounding, saturating cast, NaN -> 0
+    mn, qt, codes = orc.quantize([0.0, 255.0, 127.5, 0.5, 254.5])
+    assert (mn, qt) == (0.0, 1.0) and codes.tolist() == [0, 255, 128, 1, 255]
+    mn, qt, codes = orc.quantize([2.5, 2.5, 2.5])
+    assert mn == 2.5 and qt == 0.0 and codes.tolist() == [0, 0, 0]
+    mn, qt, codes = orc.quantize([1.0])
+    assert codes.tolist() == [0]
+
+
+def test_f16_roundtrip_matches_numpy():
+    L = orc.lib()
+    allh = np.arange(65536, dtype=np.uint16)
+    asf = allh.view(np.float16).astype(np.float32)
+    for h in list(range(0, 65536, 7)) + [0x7bff, 0xfbff, 0x0001, 0x03ff, 0x0400]:
+        f = L.orc_f16_to_f32(h)
+        if np.isnan(asf[h]):
+            assert np.isnan(f)
+        else:
+            assert f == asf[h]
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.normal(0, 3, 5000), rng.uniform(-70000, 70000, 2000),
+                         rng.uniform(-1e-5, 1e-5, 2000), [65504, 65519.9, 65520, 1e9, -1e9, 0.0, -0.0,
+                                                          2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -25]]).astype(np.float32)
+    for x in xs:
+        got = L.orc_f32_to_f16(float(x))
+        with np.errstate(over="ignore"):
+            ref = np.float32(x).astype(np.float16)
+        if np.isinf(ref):  # saturating, not IEEE overflow-to-inf
+            assert got == (0x7bff if x > 0 else 0xfbff)
+        else:
+            assert got == int(ref.view(np.uint16)), (x, got)
