@@ -190,8 +190,9 @@ sgpu_status sgpu_batch_create(sgpu_index* idx, const uint64_t* q_off,
 sgpu_status sgpu_batch_run(sgpu_index* idx, sgpu_batch* batch,
                            const sgpu_search_params* params, int32_t sync,
                            sgpu_launch_stats* stats);
-/* Blocks until all enqueued passes are done. */
-sgpu_status sgpu_batch_sync(sgpu_index* idx);
+/* Blocks until all enqueued passes are done; *stats (may be NULL) gets the MEAN
+ * kernel duration of the passes enqueued since the previous sync. */
+sgpu_status sgpu_batch_sync(sgpu_index* idx, sgpu_launch_stats* stats);
 sgpu_status sgpu_batch_fetch(sgpu_index* idx, sgpu_batch* batch, uint32_t k,
                              float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n);
 void sgpu_batch_destroy(sgpu_batch* batch);

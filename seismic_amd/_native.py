@@ -1,0 +1,254 @@
+"""ctypes binding of libseismic_hip.so (the C ABI in include/seismic_hip.h).
+
+The library is built in-tree by seismic_amd/csrc/Makefile. There is no Python or
+CPU fallback for the search path: if the shared object is missing, or no HIP
+device is usable, the calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import (ABI_VERSION, BuildConfig, IndexDesc, LaunchStats, SearchParams, SynthSpec,
+                   SGPU_OK)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libseismic_hip.so")
+_lib = None
+
+
+class SeismicHipError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("seismic_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `make -C seismic_amd/csrc` (needs hipcc); "
+                "there is no CPU fallback for the search path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.sgpu_last_error.restype = C.c_char_p
+        L.sgpu_abi_version.restype = C.c_uint32
+        L.sgpu_index_device_bytes.restype = C.c_uint64
+        L.sgpu_index_device_bytes.argtypes = [C.c_void_p]
+        L.sgpu_index_destroy.argtypes = [C.c_void_p]
+        L.sgpu_index_destroy.restype = None
+        L.sgpu_batch_destroy.argtypes = [C.c_void_p]
+        L.sgpu_batch_destroy.restype = None
+        vp = C.c_void_p
+        L.sgpu_device_count.argtypes = [C.POINTER(C.c_int32)]
+        L.sgpu_index_create.argtypes = [C.POINTER(IndexDesc), C.POINTER(vp)]
+        L.sgpu_index_build.argtypes = [C.c_uint32, C.c_uint64, C.c_uint64, vp, vp, vp,
+                                       C.POINTER(BuildConfig), C.POINTER(vp)]
+        L.sgpu_index_get_desc.argtypes = [vp, C.POINTER(IndexDesc)]
+        L.sgpu_index_save.argtypes = [vp, C.c_char_p]
+        L.sgpu_index_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.sgpu_index_upload.argtypes = [vp, C.c_int32]
+        L.sgpu_search.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp,
+                                  C.POINTER(C.c_uint32)]
+        L.sgpu_batch_search.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp, vp]
+        L.sgpu_batch_create.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
+        L.sgpu_batch_run.argtypes = [vp, vp, C.POINTER(SearchParams), C.c_int32, C.POINTER(LaunchStats)]
+        L.sgpu_batch_sync.argtypes = [vp, C.POINTER(LaunchStats)]
+        L.sgpu_batch_fetch.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
+        L.sgpu_summary_distances.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
+        L.sgpu_exact_search.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+        L.sgpu_synth_generate.argtypes = [C.POINTER(SynthSpec), vp, vp, vp, C.c_uint64, vp, vp, vp,
+                                          C.POINTER(C.c_uint64)]
+        if L.sgpu_abi_version() != ABI_VERSION:
+            raise ImportError("libseismic_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != SGPU_OK:
+        raise SeismicHipError(status, lib().sgpu_last_error().decode("utf-8", "replace"))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int32(0)
+    st = lib().sgpu_device_count(C.byref(n))
+    return n.value if st == SGPU_OK else 0
+
+
+def params(k, query_cut, heap_factor, first_sorted, n_knn=0):
+    return SearchParams(k=int(k), query_cut=int(query_cut), heap_factor=float(heap_factor),
+                        n_knn=int(n_knn), first_sorted=1 if first_sorted else 0)
+
+
+def _csr(q_off, comps, vals):
+    return (np.ascontiguousarray(q_off, np.uint64), np.ascontiguousarray(comps, np.uint32),
+            np.ascontiguousarray(vals, np.float32))
+
+
+class NativeIndex:
+    """Owns an sgpu_index handle."""
+
+    def __init__(self, handle):
+        self.h = C.c_void_p(handle)
+        self._desc = None
+
+    @classmethod
+    def build(cls, comp_width, dim, offsets, comps, vals, cfg=None):
+        cfg = cfg or BuildConfig.defaults()
+        offsets = np.ascontiguousarray(offsets, np.uint64)
+        cdt = np.uint16 if comp_width == 2 else np.uint32
+        comps = np.ascontiguousarray(comps, cdt)
+        vals = np.ascontiguousarray(vals, np.float32)
+        h = C.c_void_p()
+        check(lib().sgpu_index_build(comp_width, len(offsets) - 1, dim, _p(offsets), _p(comps), _p(vals),
+                                     C.byref(cfg), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_desc(cls, desc):
+        h = C.c_void_p()
+        check(lib().sgpu_index_create(C.byref(desc), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        check(lib().sgpu_index_load(os.fsencode(path), C.byref(h)))
+        return cls(h.value)
+
+    def save(self, path):
+        check(lib().sgpu_index_save(self.h, os.fsencode(path)))
+
+    @property
+    def desc(self):
+        if self._desc is None:
+            d = IndexDesc()
+            check(lib().sgpu_index_get_desc(self.h, C.byref(d)))
+            self._desc = d
+        return self._desc
+
+    def upload(self, device=0):
+        check(lib().sgpu_index_upload(self.h, int(device)))
+        return self
+
+    def device_bytes(self):
+        return int(lib().sgpu_index_device_bytes(self.h))
+
+    def close(self):
+        if self.h:
+            lib().sgpu_index_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- search ----
+    def search(self, comps, vals, k, query_cut, heap_factor, first_sorted=False, n_knn=0):
+        comps = np.ascontiguousarray(comps, np.uint32)
+        vals = np.ascontiguousarray(vals, np.float32)
+        sc = np.zeros(max(k, 1), np.float32)
+        ids = np.zeros(max(k, 1), np.uint64)
+        n = C.c_uint32(0)
+        p = params(k, query_cut, heap_factor, first_sorted, n_knn)
+        check(lib().sgpu_search(self.h, _p(comps), _p(vals), len(comps), C.byref(p), _p(sc), _p(ids),
+                                C.byref(n)))
+        return sc[: n.value].copy(), ids[: n.value].copy()
+
+    def batch_search(self, q_off, comps, vals, k, query_cut, heap_factor, first_sorted=False, n_knn=0):
+        q_off, comps, vals = _csr(q_off, comps, vals)
+        nq = len(q_off) - 1
+        sc = np.zeros((nq, max(k, 1)), np.float32)
+        ids = np.zeros((nq, max(k, 1)), np.uint64)
+        n = np.zeros(max(nq, 1), np.uint32)
+        p = params(k, query_cut, heap_factor, first_sorted, n_knn)
+        check(lib().sgpu_batch_search(self.h, _p(q_off), _p(comps), _p(vals), nq, C.byref(p), _p(sc),
+                                      _p(ids), _p(n)))
+        return sc, ids, n[:nq]
+
+    def summary_distances(self, list_id, comps, vals):
+        comps = np.ascontiguousarray(comps, np.uint32)
+        vals = np.ascontiguousarray(vals, np.float32)
+        out = np.zeros(65536, np.float32)
+        n = C.c_uint32(0)
+        check(lib().sgpu_summary_distances(self.h, int(list_id), _p(comps), _p(vals), len(comps), _p(out),
+                                           C.byref(n)))
+        return out[: n.value].copy()
+
+    def exact_search(self, q_off, comps, vals, k, num_threads=0):
+        q_off, comps, vals = _csr(q_off, comps, vals)
+        nq = len(q_off) - 1
+        sc = np.zeros((nq, k), np.float32)
+        ids = np.zeros((nq, k), np.uint64)
+        n = np.zeros(max(nq, 1), np.uint32)
+        check(lib().sgpu_exact_search(self.h, _p(q_off), _p(comps), _p(vals), nq, k, num_threads, _p(sc),
+                                      _p(ids), _p(n)))
+        return sc, ids, n[:nq]
+
+
+class DeviceBatch:
+    """A query batch resident in HBM (what bench.py times)."""
+
+    def __init__(self, index, q_off, comps, vals, k_max):
+        self.index = index
+        self.q_off, self.comps, self.vals = _csr(q_off, comps, vals)
+        self.nq = len(self.q_off) - 1
+        self.k_max = int(k_max)
+        self.h = C.c_void_p()
+        check(lib().sgpu_batch_create(index.h, _p(self.q_off), _p(self.comps), _p(self.vals), self.nq,
+                                      self.k_max, C.byref(self.h)))
+
+    def run(self, k, query_cut, heap_factor, first_sorted=False, sync=True):
+        p = params(k, query_cut, heap_factor, first_sorted)
+        st = LaunchStats()
+        check(lib().sgpu_batch_run(self.index.h, self.h, C.byref(p), 1 if sync else 0, C.byref(st)))
+        return st
+
+    def sync(self):
+        st = LaunchStats()
+        check(lib().sgpu_batch_sync(self.index.h, C.byref(st)))
+        return st
+
+    def fetch(self, k):
+        sc = np.zeros((self.nq, k), np.float32)
+        ids = np.zeros((self.nq, k), np.uint64)
+        n = np.zeros(max(self.nq, 1), np.uint32)
+        check(lib().sgpu_batch_fetch(self.index.h, self.h, k, _p(sc), _p(ids), _p(n)))
+        return sc, ids, n[: self.nq]
+
+    def close(self):
+        if self.h:
+            lib().sgpu_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def synth(n_vecs, dim, seed, kind=0, docs=None):
+    """SPLADE-shaped synthetic CSR (offsets u64, comps u32, vals f32). kind 0 docs, 1 queries."""
+    spec = SynthSpec(n_vecs=n_vecs, dim=dim, seed=seed, kind=kind)
+    nnz = C.c_uint64(0)
+    d_off = d_c = d_v = None
+    nd = 0
+    if kind == 1:
+        d_off, d_c, d_v = _csr(*docs)
+        nd = len(d_off) - 1
+    check(lib().sgpu_synth_generate(C.byref(spec), _p(d_off), _p(d_c), _p(d_v), nd, None, None, None,
+                                    C.byref(nnz)))
+    off = np.zeros(n_vecs + 1, np.uint64)
+    comps = np.zeros(max(nnz.value, 1), np.uint32)
+    vals = np.zeros(max(nnz.value, 1), np.float32)
+    check(lib().sgpu_synth_generate(C.byref(spec), _p(d_off), _p(d_c), _p(d_v), nd, _p(off), _p(comps),
+                                    _p(vals), C.byref(nnz)))
+    return off, comps[: nnz.value], vals[: nnz.value]

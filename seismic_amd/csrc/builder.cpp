@@ -1,0 +1,522 @@
+// builder.cpp — CPU index construction (offline, host cores).
+//
+// What it computes follows the reference's build for the configuration its
+// Python API exposes (src/pylib/mod.rs:329-369):
+//   GlobalThreshold pruning            src/inverted_index.rs:354-389
+//   RandomKmeansInvertedIndexApprox    src/posting_list.rs:227-300, src/utils.rs:106-237
+//   EnergyPreserving summaries         src/posting_list.rs:329-368
+//   u8 scalar quantisation             src/utils.rs:68-90
+//   per-list summary CSR               src/quantized_summary.rs:297-405
+// How it computes it is built for 10^6..10^7 documents: a histogram over the
+// 65536 binary16 patterns finds the global threshold in one pass (no sort of
+// all entries), posting lists are filled by a counting pass, and every list is
+// clustered / summarised independently on all host cores with dense per-thread
+// scratch (no hash maps). Tie-breaking rules where the reference is
+// unspecified are documented in DESIGN.md ("Restated choices") and are the same
+// as the oracle's, so both builders produce the identical index.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <numeric>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "host_index.hpp"
+
+namespace sgpu {
+namespace {
+
+struct Docs {
+  uint64_t n_docs, dim;
+  const uint64_t* off;
+  const uint32_t* comps;  // widened
+  const uint16_t* vals;
+};
+
+struct TopC {  // a document's doc_cut heaviest components, heaviest first
+  uint32_t c;
+  float v;
+};
+
+// quantize (src/utils.rs:68-90): round half away from zero, saturating u8 cast, NaN -> 0.
+inline void quantize_block(const float* v, size_t n, float* mn_out, float* qt_out, uint8_t* codes) {
+  float mn = v[0], mx = v[0];
+  for (size_t i = 1; i < n; ++i) {
+    if (total_key(v[i]) < total_key(mn)) mn = v[i];
+    if (total_key(v[i]) >= total_key(mx)) mx = v[i];
+  }
+  const float quant = (mx - mn) / 255.0f;
+  for (size_t i = 0; i < n; ++i) {
+    const float r = std::round((v[i] - mn) / quant);
+    codes[i] = std::isnan(r) ? 0 : (r <= 0.0f ? 0 : (r >= 255.0f ? 255 : (uint8_t)r));
+  }
+  *mn_out = mn;
+  *qt_out = quant;
+}
+
+// Per-thread scratch, sized once.
+struct Scratch {
+  // centroid inverted file (component -> [(centroid id, value)]) as a touched-reset CSR
+  std::vector<uint32_t> comp_cnt, comp_pos;  // dim
+  std::vector<uint32_t> touched_comps;
+  std::vector<uint32_t> inv_cid;
+  std::vector<float> inv_val;
+  std::vector<float> scores;  // n_centroids
+  std::vector<uint32_t> touched_c;
+  std::vector<uint8_t> avoided, is_touched;
+  // summaries
+  std::vector<float> maxv;  // dim, NaN-free sentinel via has[]
+  std::vector<uint8_t> has;
+  std::vector<uint32_t> scomps;
+  explicit Scratch(uint64_t dim) : comp_cnt(dim, 0), comp_pos(dim, 0), maxv(dim, 0.0f), has(dim, 0) {}
+};
+
+struct ListOut {
+  std::vector<uint32_t> post;          // reordered doc ids
+  std::vector<uint32_t> block_off;     // nb + 1 (local)
+  std::vector<float> mins, quants;     // nb
+  std::vector<uint32_t> row_comp;      // rows
+  std::vector<uint32_t> row_ptr;       // rows + 1 (local)
+  std::vector<uint16_t> bid;
+  std::vector<uint8_t> code;
+};
+
+// compute_centroid_assignments_approx_dot_product (src/utils.rs:106-144) without
+// the O(n_centroids) reset/scan per document: only centroids reached through the
+// document's top components can differ from +0.0.
+void assign_docs(const std::vector<uint32_t>& docs, const std::vector<uint32_t>& centroid_docs,
+                 const std::vector<TopC>& top, uint32_t doc_cut, Scratch& s,
+                 std::vector<std::pair<uint32_t, uint32_t>>& out) {
+  const size_t nc = centroid_docs.size();
+  // largest non-avoided centroid index and, lazily, the largest untouched one
+  for (uint32_t doc : docs) {
+    s.touched_c.clear();
+    const TopC* t = &top[(size_t)doc * doc_cut];
+    for (uint32_t i = 0; i < doc_cut && t[i].c != 0xffffffffu; ++i) {
+      const uint32_t c = t[i].c;
+      const uint32_t n = s.comp_cnt[c];
+      if (!n) continue;
+      const uint32_t p0 = s.comp_pos[c];
+      const float dv = t[i].v;
+      for (uint32_t e = 0; e < n; ++e) {
+        const uint32_t cid = s.inv_cid[p0 + e];
+        if (!s.is_touched[cid]) {
+          s.is_touched[cid] = 1;
+          s.touched_c.push_back(cid);
+        }
+        s.scores[cid] = s.scores[cid] + s.inv_val[p0 + e] * dv;
+      }
+    }
+    // argmax by (total_cmp key, index): Rust max_by keeps the LAST maximum.
+    int64_t best = -1;
+    int32_t best_key = 0;
+    for (uint32_t cid : s.touched_c) {
+      if (s.avoided[cid]) continue;
+      const int32_t k = total_key(s.scores[cid]);
+      if (best < 0 || k > best_key || (k == best_key && (int64_t)cid > best)) {
+        best = cid;
+        best_key = k;
+      }
+    }
+    // best untouched non-avoided centroid: score +0.0, largest index
+    int64_t u = (int64_t)nc - 1;
+    while (u >= 0 && (s.avoided[(size_t)u] || s.is_touched[(size_t)u])) --u;
+    if (u >= 0) {
+      const int32_t k0 = total_key(0.0f);
+      if (best < 0 || k0 > best_key || (k0 == best_key && u > best)) best = u;
+    }
+    const uint32_t cdoc = best < 0 ? centroid_docs[0] : centroid_docs[(size_t)best];
+    out.emplace_back(cdoc, doc);
+    for (uint32_t cid : s.touched_c) {
+      s.scores[cid] = 0.0f;
+      s.is_touched[cid] = 0;
+    }
+  }
+}
+
+void build_list(const Docs& d, const std::vector<uint32_t>& postings_by_value, const sgpu_build_config& cfg,
+                const std::vector<TopC>& top, Scratch& s, ListOut& o) {
+  const size_t len = postings_by_value.size();
+  if (len == 0) {
+    o.block_off.clear();
+    return;
+  }
+  // ---- blocking_with_random_kmeans (src/posting_list.rs:227-300) ----
+  const size_t n_centroids = std::max<size_t>(1, (size_t)(cfg.centroid_fraction * (float)len));
+  SplitMix64 rng(1142);  // seed of src/utils.rs:163
+  std::vector<uint32_t> pool(postings_by_value);
+  const size_t nc = std::min(n_centroids, len);
+  std::vector<uint32_t> centroid_docs(nc);
+  for (size_t i = 0; i < nc; ++i) {
+    const size_t j = i + (size_t)rng.below(len - i);
+    std::swap(pool[i], pool[j]);
+    centroid_docs[i] = pool[i];
+  }
+  // centroid inverted file
+  s.touched_comps.clear();
+  size_t total = 0;
+  for (uint32_t cd : centroid_docs)
+    for (uint64_t i = d.off[cd]; i < d.off[cd + 1]; ++i) {
+      if (s.comp_cnt[d.comps[i]]++ == 0) s.touched_comps.push_back(d.comps[i]);
+      ++total;
+    }
+  s.inv_cid.resize(total);
+  s.inv_val.resize(total);
+  {
+    uint32_t run = 0;
+    for (uint32_t c : s.touched_comps) {
+      s.comp_pos[c] = run;
+      run += s.comp_cnt[c];
+      s.comp_cnt[c] = 0;  // reused as fill cursor
+    }
+    for (size_t cid = 0; cid < nc; ++cid) {
+      const uint32_t cd = centroid_docs[cid];
+      for (uint64_t i = d.off[cd]; i < d.off[cd + 1]; ++i) {
+        const uint32_t c = d.comps[i];
+        const uint32_t p = s.comp_pos[c] + s.comp_cnt[c]++;
+        s.inv_cid[p] = (uint32_t)cid;
+        s.inv_val[p] = f16_to_f32(d.vals[i]);
+      }
+    }
+  }
+  s.scores.assign(nc, 0.0f);
+  s.avoided.assign(nc, 0);
+  s.is_touched.assign(nc, 0);
+
+  std::vector<std::pair<uint32_t, uint32_t>> assign;
+  assign.reserve(len);
+  assign_docs(postings_by_value, centroid_docs, top, cfg.doc_cut, s, assign);
+  std::sort(assign.begin(), assign.end());
+  // dissolve clusters with <= min_cluster_size members (src/utils.rs:196-209)
+  std::vector<uint32_t> redo;
+  std::vector<std::pair<uint32_t, uint32_t>> fin;
+  fin.reserve(len);
+  std::vector<std::pair<uint32_t, uint32_t>> cdoc_to_cid(nc);
+  for (size_t i = 0; i < nc; ++i) cdoc_to_cid[i] = {centroid_docs[i], (uint32_t)i};
+  std::sort(cdoc_to_cid.begin(), cdoc_to_cid.end());
+  for (size_t i = 0; i < assign.size();) {
+    size_t j = i;
+    while (j < assign.size() && assign[j].first == assign[i].first) ++j;
+    if (j - i <= cfg.min_cluster_size) {
+      for (size_t t = i; t < j; ++t) redo.push_back(assign[t].second);
+      auto it = std::lower_bound(cdoc_to_cid.begin(), cdoc_to_cid.end(), std::make_pair(assign[i].first, 0u));
+      s.avoided[it->second] = 1;
+    } else {
+      fin.insert(fin.end(), assign.begin() + (long)i, assign.begin() + (long)j);
+    }
+    i = j;
+  }
+  if (!redo.empty()) {
+    std::vector<std::pair<uint32_t, uint32_t>> re;
+    re.reserve(redo.size());
+    assign_docs(redo, centroid_docs, top, cfg.doc_cut, s, re);
+    fin.insert(fin.end(), re.begin(), re.end());
+  }
+  std::sort(fin.begin(), fin.end());
+  for (uint32_t c : s.touched_comps) s.comp_cnt[c] = 0;
+
+  o.post.resize(len);
+  o.block_off.assign(1, 0);
+  for (size_t i = 0; i < fin.size();) {
+    size_t j = i;
+    while (j < fin.size() && fin[j].first == fin[i].first) ++j;
+    for (size_t t = i; t < j; ++t) o.post[t] = fin[t].second;
+    o.block_off.push_back((uint32_t)j);
+    i = j;
+  }
+  const size_t nb = o.block_off.size() - 1;
+
+  // ---- energy_preserving_summary per block + quantisation ----
+  struct Ent {
+    uint32_t comp;
+    uint16_t bid;
+    uint8_t code;
+  };
+  std::vector<Ent> ents;
+  o.mins.resize(nb);
+  o.quants.resize(nb);
+  std::vector<std::pair<float, uint32_t>> cv;  // (value, comp)
+  std::vector<float> kv;
+  std::vector<uint8_t> kc;
+  for (size_t b = 0; b < nb; ++b) {
+    s.scomps.clear();
+    for (uint32_t t = o.block_off[b]; t < o.block_off[b + 1]; ++t) {
+      const uint32_t doc = o.post[t];
+      for (uint64_t i = d.off[doc]; i < d.off[doc + 1]; ++i) {
+        const uint32_t c = d.comps[i];
+        const float v = f16_to_f32(d.vals[i]);
+        if (!s.has[c]) {
+          s.has[c] = 1;
+          s.maxv[c] = v;
+          s.scomps.push_back(c);
+        } else if (s.maxv[c] < v) {
+          s.maxv[c] = v;
+        }
+      }
+    }
+    cv.clear();
+    for (uint32_t c : s.scomps) {
+      cv.emplace_back(s.maxv[c], c);
+      s.has[c] = 0;
+    }
+    std::sort(cv.begin(), cv.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) {
+      const int32_t ka = total_key(a.first), kb = total_key(b.first);
+      if (ka != kb) return ka > kb;
+      return a.second < b.second;
+    });
+    float tot = 0.0f;
+    for (auto& x : cv) tot = tot + x.first;
+    const float until = tot * cfg.summary_energy;
+    float acc = 0.0f;
+    size_t keep = 0;
+    for (; keep < cv.size();) {  // take_while_inclusive
+      acc = acc + cv[keep].first;
+      ++keep;
+      if (!(acc < until)) break;
+    }
+    cv.resize(keep);
+    std::sort(cv.begin(), cv.end(),
+              [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.second < b.second; });
+    kv.resize(keep);
+    kc.resize(keep);
+    for (size_t i = 0; i < keep; ++i) kv[i] = cv[i].first;
+    quantize_block(kv.data(), keep, &o.mins[b], &o.quants[b], kc.data());
+    for (size_t i = 0; i < keep; ++i) ents.push_back({cv[i].second, (uint16_t)b, kc[i]});
+  }
+  // per-list summary CSR by component (src/quantized_summary.rs:303-357)
+  std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.comp < b.comp; });
+  o.row_comp.clear();
+  o.row_ptr.assign(1, 0);
+  o.bid.resize(ents.size());
+  o.code.resize(ents.size());
+  for (size_t i = 0; i < ents.size(); ++i) {
+    if (i == 0 || ents[i].comp != ents[i - 1].comp) {
+      if (i) o.row_ptr.push_back((uint32_t)i);
+      o.row_comp.push_back(ents[i].comp);
+    }
+    o.bid[i] = ents[i].bid;
+    o.code[i] = ents[i].code;
+  }
+  if (!ents.empty()) o.row_ptr.push_back((uint32_t)ents.size());
+}
+
+}  // namespace
+
+sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim, const uint64_t* offsets,
+                             const void* comps_in, const float* vals, const sgpu_build_config& cfg,
+                             HostIndex* out) {
+  if (comp_width != 2 && comp_width != 4) return fail(SGPU_EINVAL, "comp_width must be 2 or 4");
+  if (dim == 0 || (comp_width == 2 && dim > 65536)) return fail(SGPU_EINVAL, "dim out of range for comp_width");
+  if (n_docs > 0x7fffffffull) return fail(SGPU_EINVAL, "too many documents");
+  if (cfg.n_postings == 0 || cfg.doc_cut == 0) return fail(SGPU_EINVAL, "n_postings and doc_cut must be > 0");
+  if (!offsets || offsets[0] != 0) return fail(SGPU_EINVAL, "offsets[0] != 0");
+  const uint64_t nnz = offsets[n_docs];
+#ifdef _OPENMP
+  const int nt = cfg.num_threads ? (int)cfg.num_threads : omp_get_max_threads();
+#else
+  const int nt = 1;
+#endif
+  try {
+    HostIndex& h = *out;
+    h.comp_width = comp_width;
+    h.n_docs = n_docs;
+    h.dim = dim;
+    h.fwd_offsets.assign(offsets, offsets + n_docs + 1);
+    h.fwd_comps.assign((const uint8_t*)comps_in, (const uint8_t*)comps_in + nnz * comp_width);
+    h.fwd_vals.resize(nnz);
+    std::vector<uint32_t> wide(nnz);
+    std::atomic<int> bad{0};
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int64_t doc = 0; doc < (int64_t)n_docs; ++doc) {
+      const uint64_t s = offsets[doc], e = offsets[doc + 1];
+      if (e < s || e - s > 65535) bad = 1;
+      for (uint64_t i = s; i < e && i < nnz; ++i) {
+        const uint32_t c = comp_width == 2 ? (uint32_t)((const uint16_t*)comps_in)[i] : ((const uint32_t*)comps_in)[i];
+        wide[i] = c;
+        if (c >= dim || (i > s && c <= wide[i - 1])) bad = 2;
+        if (std::isnan(vals[i])) bad = 3;  // partial_cmp().unwrap() would panic (src/inverted_index.rs:377)
+        h.fwd_vals[i] = f32_to_f16_sat(vals[i]);
+      }
+    }
+    if (bad == 1) return fail(SGPU_EINVAL, "offsets not monotone or a document has > 65535 components");
+    if (bad == 2) return fail(SGPU_EINVAL, "document components must be strictly ascending and < dim");
+    if (bad == 3) return fail(SGPU_EINVAL, "NaN document value");
+    Docs d{n_docs, dim, h.fwd_offsets.data(), wide.data(), h.fwd_vals.data()};
+
+    // ---- global_threshold_pruning (src/inverted_index.rs:354-389) ----
+    // top dim*n_postings entries by value; ties by (doc asc, comp asc) = scan order.
+    const uint64_t tot = dim * cfg.n_postings;
+    std::vector<uint64_t> hist(65537, 0);  // indexed by f16_desc_key
+    {
+      std::vector<std::vector<uint64_t>> th((size_t)nt, std::vector<uint64_t>(65537, 0));
+#pragma omp parallel num_threads(nt)
+      {
+#ifdef _OPENMP
+        auto& my = th[(size_t)omp_get_thread_num()];
+#else
+        auto& my = th[0];
+#endif
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < (int64_t)nnz; ++i) my[f16_desc_key(h.fwd_vals[(size_t)i])]++;
+      }
+      for (auto& t : th)
+        for (size_t k = 0; k < 65537; ++k) hist[k] += t[k];
+    }
+    uint32_t thr_key = 65537;  // entries with key < thr_key are all kept
+    uint64_t need_eq = 0;      // plus the first need_eq entries (scan order) with key == thr_key
+    if (nnz > tot) {
+      uint64_t run = 0;
+      for (uint32_t k = 0; k < 65537; ++k) {
+        if (run + hist[k] >= tot) {
+          thr_key = k;
+          need_eq = tot - run;
+          break;
+        }
+        run += hist[k];
+      }
+    }
+    // count per list, then fill (value key, doc) pairs
+    std::vector<uint64_t> list_cnt(dim + 1, 0);
+    std::vector<uint8_t> sel(nnz, 0);
+    {
+      uint64_t eq_seen = 0;
+      for (uint64_t i = 0; i < nnz; ++i) {  // sequential: the tie rule is defined on scan order
+        const uint32_t k = f16_desc_key(h.fwd_vals[i]);
+        bool take = k < thr_key;
+        if (!take && k == thr_key && eq_seen < need_eq) {
+          take = true;
+          ++eq_seen;
+        }
+        if (take) {
+          sel[i] = 1;
+          list_cnt[wide[i] + 1]++;
+        }
+      }
+    }
+    for (uint64_t c = 0; c < dim; ++c) list_cnt[c + 1] += list_cnt[c];
+    const uint64_t n_sel = list_cnt[dim];
+    std::vector<uint64_t> pairs(n_sel);  // (desc key << 32) | doc  -> ascending sort == (value desc, doc asc)
+    {
+      std::vector<uint64_t> cur(list_cnt.begin(), list_cnt.end() - 1);
+      for (uint64_t doc = 0; doc < n_docs; ++doc)
+        for (uint64_t i = offsets[doc]; i < offsets[doc + 1]; ++i)
+          if (sel[i]) pairs[cur[wide[i]]++] = ((uint64_t)f16_desc_key(h.fwd_vals[i]) << 32) | doc;
+    }
+    sel.clear();
+    sel.shrink_to_fit();
+    const size_t cap = (size_t)((float)cfg.n_postings * cfg.max_fraction);
+
+    // every document's doc_cut heaviest components (k_largest_by, src/utils.rs:125-127),
+    // computed once instead of once per posting
+    const uint32_t dc = cfg.doc_cut;
+    std::vector<TopC> top((size_t)n_docs * dc);
+#pragma omp parallel num_threads(nt)
+    {
+      std::vector<std::pair<int32_t, uint32_t>> tmp;  // (-key, comp)
+#pragma omp for schedule(dynamic, 1024)
+      for (int64_t doc = 0; doc < (int64_t)n_docs; ++doc) {
+        tmp.clear();
+        for (uint64_t i = offsets[doc]; i < offsets[doc + 1]; ++i)
+          tmp.emplace_back(total_key(f16_to_f32(h.fwd_vals[i])), wide[i]);
+        auto cmp = [](const std::pair<int32_t, uint32_t>& a, const std::pair<int32_t, uint32_t>& b) {
+          if (a.first != b.first) return a.first > b.first;
+          return a.second < b.second;
+        };
+        const size_t kk = std::min<size_t>(dc, tmp.size());
+        std::partial_sort(tmp.begin(), tmp.begin() + (long)kk, tmp.end(), cmp);
+        TopC* t = &top[(size_t)doc * dc];
+        for (size_t i = 0; i < dc; ++i) {
+          if (i < kk) {
+            t[i].c = tmp[i].second;
+            int32_t kb = tmp[i].first;  // invert total_key
+            kb ^= (int32_t)(((uint32_t)(kb >> 31)) >> 1);
+            std::memcpy(&t[i].v, &kb, 4);
+          } else {
+            t[i].c = 0xffffffffu;
+            t[i].v = 0.0f;
+          }
+        }
+      }
+    }
+
+    // ---- per list ----
+    std::vector<ListOut> outs(dim);
+    std::atomic<int> limit_err{0};
+#pragma omp parallel num_threads(nt)
+    {
+      Scratch s(dim);
+      std::vector<uint32_t> pl;
+#pragma omp for schedule(dynamic, 8)
+      for (int64_t c = 0; c < (int64_t)dim; ++c) {
+        uint64_t a = list_cnt[(size_t)c], b = list_cnt[(size_t)c + 1];
+        if (a == b) continue;
+        std::sort(pairs.begin() + (long)a, pairs.begin() + (long)b);
+        const size_t len = std::min<size_t>(b - a, cap);
+        if (len == 0) continue;
+        if ((size_t)(cfg.centroid_fraction * (float)len) > 65535) {
+          limit_err = 1;  // src/posting_list.rs:243-246
+          continue;
+        }
+        pl.resize(len);
+        for (size_t i = 0; i < len; ++i) pl[i] = (uint32_t)(pairs[a + i] & 0xffffffffu);
+        build_list(d, pl, cfg, top, s, outs[(size_t)c]);
+      }
+    }
+    if (limit_err) return fail(SGPU_ELIMIT, "a posting list needs more than 65535 centroids; decrease centroid_fraction");
+    pairs.clear();
+    pairs.shrink_to_fit();
+    top.clear();
+    top.shrink_to_fit();
+
+    // ---- concatenate ----
+    h.list_block_start.assign(dim + 1, 0);
+    h.list_row_start.assign(dim + 1, 0);
+    std::vector<uint64_t> post_base(dim + 1, 0), ent_base(dim + 1, 0);
+    for (uint64_t c = 0; c < dim; ++c) {
+      const ListOut& o = outs[c];
+      const uint64_t nb = o.block_off.empty() ? 0 : o.block_off.size() - 1;
+      h.list_block_start[c + 1] = h.list_block_start[c] + nb;
+      h.list_row_start[c + 1] = h.list_row_start[c] + o.row_comp.size();
+      post_base[c + 1] = post_base[c] + o.post.size();
+      ent_base[c + 1] = ent_base[c] + o.bid.size();
+    }
+    const uint64_t NB = h.list_block_start[dim], NR = h.list_row_start[dim];
+    h.block_post_start.assign(NB + 1, 0);
+    h.post_doc.resize(post_base[dim]);
+    h.blk_min.resize(NB);
+    h.blk_quant.resize(NB);
+    h.row_comp.resize(NR * comp_width);
+    h.row_ptr.assign(NR + 1, 0);
+    h.sum_bid.resize(ent_base[dim]);
+    h.sum_code.resize(ent_base[dim]);
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+    for (int64_t c = 0; c < (int64_t)dim; ++c) {
+      const ListOut& o = outs[(size_t)c];
+      const uint64_t b0 = h.list_block_start[(size_t)c], r0 = h.list_row_start[(size_t)c];
+      const uint64_t nb = o.block_off.empty() ? 0 : o.block_off.size() - 1;
+      for (uint64_t b = 0; b < nb; ++b) {
+        h.block_post_start[b0 + b + 1] = post_base[(size_t)c] + o.block_off[b + 1];
+        h.blk_min[b0 + b] = o.mins[b];
+        h.blk_quant[b0 + b] = o.quants[b];
+      }
+      std::copy(o.post.begin(), o.post.end(), h.post_doc.begin() + (long)post_base[(size_t)c]);
+      for (size_t r = 0; r < o.row_comp.size(); ++r) {
+        if (comp_width == 2) ((uint16_t*)h.row_comp.data())[r0 + r] = (uint16_t)o.row_comp[r];
+        else ((uint32_t*)h.row_comp.data())[r0 + r] = o.row_comp[r];
+        h.row_ptr[r0 + r + 1] = ent_base[(size_t)c] + o.row_ptr[r + 1];
+      }
+      std::copy(o.bid.begin(), o.bid.end(), h.sum_bid.begin() + (long)ent_base[(size_t)c]);
+      std::copy(o.code.begin(), o.code.end(), h.sum_code.begin() + (long)ent_base[(size_t)c]);
+    }
+    // block_post_start[b0] of an empty-list boundary: fill forward so the array is monotone
+    // (entries written above are exact; index 0 stays 0 and every list's first block starts
+    // at post_base[c], which equals the previous list's last value).
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of host memory building the index");
+  }
+  return SGPU_OK;
+}
+
+}  // namespace sgpu

@@ -1,0 +1,512 @@
+// device_index.hip — HBM residency of an index, launch configuration, query batches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <mutex>
+#include <vector>
+
+#include "device_types.hpp"
+#include "host_index.hpp"
+
+namespace sgpu {
+
+hipError_t occupancy_search(const LaunchArgs& a, int* blocks_per_cu);   // search_kernel.hip
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(SGPU_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct DeviceIndex {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  DevView view{};
+  uint32_t comp_width = 2;
+  std::vector<void*> allocs;
+  uint64_t bytes = 0;
+  uint32_t n_cu = 0;
+  uint32_t max_lds = 0;
+  std::vector<uint32_t> nb_sorted_prefix;   // prefix sums of list block counts, largest first (<= 64)
+  uint32_t max_nb = 0;
+  // per-launch scratch
+  uint32_t* queue = nullptr;
+  uint32_t* bitmaps = nullptr;
+  uint32_t bitmaps_slots = 0;
+  // timing of enqueued launches
+  static constexpr int kEvents = 64;
+  hipEvent_t ev0[kEvents], ev1[kEvents];
+  int ev_pending = 0;
+  bool ev_ready = false;
+  double sum_ms = 0;
+  uint32_t n_timed = 0;
+  sgpu_launch_stats last{};
+  std::mutex mu;
+};
+
+template <class T>
+static sgpu_status dev_copy(DeviceIndex* d, const T* src, size_t n, const T** out) {
+  void* p = nullptr;
+  const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+  if (hipMalloc(&p, bytes) != hipSuccess) return fail(SGPU_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
+  d->allocs.push_back(p);
+  d->bytes += bytes;
+  if (n) HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  *out = (const T*)p;
+  return SGPU_OK;
+}
+
+void device_index_free(DeviceIndex* d) {
+  if (!d) return;
+  if (d->device >= 0) (void)hipSetDevice(d->device);
+  if (d->stream) (void)hipStreamSynchronize(d->stream);
+  for (void* p : d->allocs) (void)hipFree(p);
+  if (d->queue) (void)hipFree(d->queue);
+  if (d->bitmaps) (void)hipFree(d->bitmaps);
+  if (d->ev_ready)
+    for (int i = 0; i < DeviceIndex::kEvents; ++i) {
+      (void)hipEventDestroy(d->ev0[i]);
+      (void)hipEventDestroy(d->ev1[i]);
+    }
+  if (d->stream) (void)hipStreamDestroy(d->stream);
+  delete d;
+}
+
+uint64_t device_index_bytes(const DeviceIndex* d) { return d ? d->bytes : 0; }
+
+int device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// Packs the canonical arrays into the HBM layout and copies them to `device`.
+sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** out) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(SGPU_EDEVICE, "no HIP device available (the search path has no CPU fallback)");
+  if (device < 0 || device >= n_dev) return fail(SGPU_EDEVICE, "device %d out of range (0..%d)", device, n_dev - 1);
+  if (h.n_blocks() >= 0xffffffffull || h.n_postings() >= 0xffffffffull || h.n_rows() >= 0xffffffffull ||
+      h.n_entries() >= 0xffffffffull)
+    return fail(SGPU_ELIMIT, "index too large for 32-bit device offsets");
+  HIP_TRY(hipSetDevice(device));
+  DeviceIndex* d = new DeviceIndex();
+  d->device = device;
+  d->comp_width = h.comp_width;
+  sgpu_status st = SGPU_OK;
+  auto bail = [&](sgpu_status s) {
+    device_index_free(d);
+    return s;
+  };
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(fail(SGPU_EDEVICE, "hipGetDeviceProperties failed"));
+  d->n_cu = (uint32_t)prop.multiProcessorCount;
+  d->max_lds = (uint32_t)prop.sharedMemPerBlock;
+  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(fail(SGPU_EDEVICE, "hipStreamCreate failed"));
+  for (int i = 0; i < DeviceIndex::kEvents; ++i) {
+    if (hipEventCreate(&d->ev0[i]) != hipSuccess || hipEventCreate(&d->ev1[i]) != hipSuccess)
+      return bail(fail(SGPU_EDEVICE, "hipEventCreate failed"));
+  }
+  d->ev_ready = true;
+
+  try {
+    const uint32_t cw = h.comp_width;
+    // ---- document records: [npad comps][npad f16], npad = len rounded up to 8, 16-byte aligned
+    std::vector<uint64_t> rec_off16(h.n_docs + 1, 0);
+    for (uint64_t doc = 0; doc < h.n_docs; ++doc) {
+      const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
+      const uint64_t npad = (len + 7) & ~7ull;
+      rec_off16[doc + 1] = rec_off16[doc] + npad * (cw + 2) / 16;
+    }
+    if (rec_off16[h.n_docs] >= (1ull << 48)) return bail(fail(SGPU_ELIMIT, "forward index exceeds 48-bit record offsets"));
+    std::vector<uint8_t> fwd(std::max<uint64_t>(rec_off16[h.n_docs] * 16, 16), 0);
+#pragma omp parallel for schedule(static)
+    for (int64_t doc = 0; doc < (int64_t)h.n_docs; ++doc) {
+      const uint64_t s0 = h.fwd_offsets[(size_t)doc], len = h.fwd_offsets[(size_t)doc + 1] - s0;
+      const uint64_t npad = (len + 7) & ~7ull;
+      uint8_t* rec = fwd.data() + rec_off16[(size_t)doc] * 16;
+      std::memcpy(rec, h.fwd_comps.data() + s0 * cw, len * cw);
+      std::memcpy(rec + npad * cw, h.fwd_vals.data() + s0, len * 2);
+    }
+    if ((st = dev_copy(d, fwd.data(), fwd.size(), &d->view.fwd)) != SGPU_OK) return bail(st);
+    fwd.clear();
+    fwd.shrink_to_fit();
+    // ---- postings
+    std::vector<uint64_t> pref(h.n_postings());
+#pragma omp parallel for schedule(static)
+    for (int64_t p = 0; p < (int64_t)pref.size(); ++p) {
+      const uint32_t doc = h.post_doc[(size_t)p];
+      const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
+      pref[(size_t)p] = (rec_off16[doc] << 16) | len;
+    }
+    if ((st = dev_copy(d, pref.data(), pref.size(), &d->view.post_ref)) != SGPU_OK) return bail(st);
+    pref.clear();
+    pref.shrink_to_fit();
+    if ((st = dev_copy(d, h.post_doc.data(), h.post_doc.size(), &d->view.post_doc)) != SGPU_OK) return bail(st);
+    auto narrow = [](const std::vector<uint64_t>& v) {
+      std::vector<uint32_t> o(v.size());
+      for (size_t i = 0; i < v.size(); ++i) o[i] = (uint32_t)v[i];
+      return o;
+    };
+    {
+      auto v = narrow(h.list_block_start);
+      if ((st = dev_copy(d, v.data(), v.size(), &d->view.list_block_start)) != SGPU_OK) return bail(st);
+      v = narrow(h.block_post_start);
+      if ((st = dev_copy(d, v.data(), v.size(), &d->view.block_post_start)) != SGPU_OK) return bail(st);
+      v = narrow(h.list_row_start);
+      if ((st = dev_copy(d, v.data(), v.size(), &d->view.list_row_start)) != SGPU_OK) return bail(st);
+      v = narrow(h.row_ptr);
+      if ((st = dev_copy(d, v.data(), v.size(), &d->view.row_ptr)) != SGPU_OK) return bail(st);
+    }
+    {
+      std::vector<float2> mq(h.n_blocks());
+      for (size_t b = 0; b < mq.size(); ++b) mq[b] = make_float2(h.blk_min[b], h.blk_quant[b]);
+      if ((st = dev_copy(d, mq.data(), mq.size(), &d->view.blk_mq)) != SGPU_OK) return bail(st);
+    }
+    {
+      const uint8_t* rc = nullptr;
+      if ((st = dev_copy(d, h.row_comp.data(), h.row_comp.size(), &rc)) != SGPU_OK) return bail(st);
+      d->view.row_comp = rc;
+    }
+    if ((st = dev_copy(d, h.sum_bid.data(), h.sum_bid.size(), &d->view.sum_bid)) != SGPU_OK) return bail(st);
+    if ((st = dev_copy(d, h.sum_code.data(), h.sum_code.size(), &d->view.sum_code)) != SGPU_OK) return bail(st);
+    d->view.dim = (uint32_t)h.dim;
+    d->view.n_docs = (uint32_t)h.n_docs;
+    d->view.n_bitmap_words = (uint32_t)((h.n_docs + 31) / 32);
+    // ---- block-count statistics for LDS sizing
+    std::vector<uint32_t> nbs(h.dim);
+    for (uint64_t c = 0; c < h.dim; ++c) nbs[c] = (uint32_t)(h.list_block_start[c + 1] - h.list_block_start[c]);
+    const size_t top = std::min<size_t>(64, nbs.size());
+    std::partial_sort(nbs.begin(), nbs.begin() + (long)top, nbs.end(), std::greater<uint32_t>());
+    d->nb_sorted_prefix.assign(top + 1, 0);
+    for (size_t i = 0; i < top; ++i) d->nb_sorted_prefix[i + 1] = d->nb_sorted_prefix[i] + nbs[i];
+    d->max_nb = top ? nbs[0] : 0;
+    if (hipMalloc((void**)&d->queue, 256) != hipSuccess) return bail(fail(SGPU_ENOMEM, "hipMalloc(queue) failed"));
+  } catch (const std::bad_alloc&) {
+    return bail(fail(SGPU_ENOMEM, "out of host memory packing the index for upload"));
+  }
+  *out = d;
+  return SGPU_OK;
+}
+
+// ---------------------------------------------------------------------------
+// batches
+// ---------------------------------------------------------------------------
+}  // namespace sgpu
+
+struct sgpu_batch {
+  int device = -1;
+  uint32_t nq = 0, k_max = 0, max_nnz = 0;
+  uint32_t* q_off = nullptr;
+  uint32_t* q_comp = nullptr;
+  float* q_val = nullptr;
+  float* out_scores = nullptr;
+  uint64_t* out_ids = nullptr;
+  uint32_t* out_n = nullptr;
+};
+
+namespace sgpu {
+
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* v = std::getenv(name);
+  if (!v || !*v) return dflt;
+  return (uint32_t)std::strtoul(v, nullptr, 10);
+}
+
+sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t* comps, const float* vals,
+                             uint32_t nq, uint32_t* max_nnz) {
+  if (!q_off || q_off[0] != 0) return fail(SGPU_EINVAL, "q_off[0] must be 0");
+  uint32_t mx = 0;
+  for (uint32_t q = 0; q < nq; ++q) {
+    if (q_off[q + 1] < q_off[q]) return fail(SGPU_EINVAL, "q_off not monotone");
+    const uint64_t n = q_off[q + 1] - q_off[q];
+    if (n > 0xffffu) return fail(SGPU_ELIMIT, "query %u has %llu components (limit 65535)", q, (unsigned long long)n);
+    mx = std::max<uint32_t>(mx, (uint32_t)n);
+    for (uint64_t i = q_off[q]; i < q_off[q + 1]; ++i) {
+      // InvertedIndexBase::search asserts sorted components (reference src/inverted_index.rs:172-175)
+      // and indexes posting_lists[component] (bounds panic, :193); duplicates are rejected too.
+      if (comps[i] >= dim) return fail(SGPU_EINVAL, "query %u: component %u >= dim", q, comps[i]);
+      if (i > q_off[q] && comps[i] <= comps[i - 1])
+        return fail(SGPU_EINVAL, "query %u: components must be strictly ascending", q);
+      if (std::isnan(vals[i])) return fail(SGPU_EINVAL, "query %u: NaN value", q);
+    }
+  }
+  if (q_off[nq] >= 0xffffffffull) return fail(SGPU_ELIMIT, "batch too large");
+  *max_nnz = mx;
+  return SGPU_OK;
+}
+
+void batch_free(sgpu_batch* b) {
+  if (!b) return;
+  if (b->device >= 0) (void)hipSetDevice(b->device);
+  (void)hipFree(b->q_off);
+  (void)hipFree(b->q_comp);
+  (void)hipFree(b->q_val);
+  (void)hipFree(b->out_scores);
+  (void)hipFree(b->out_ids);
+  (void)hipFree(b->out_n);
+  delete b;
+}
+
+sgpu_status batch_create(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
+                         const float* vals, uint32_t nq, uint32_t k_max, sgpu_batch** out) {
+  if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
+  if (k_max == 0) return fail(SGPU_EINVAL, "k == 0");
+  if (k_max > 1024) return fail(SGPU_ELIMIT, "k = %u exceeds the register heap limit of 1024", k_max);
+  uint32_t max_nnz = 0;
+  sgpu_status st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz);
+  if (st != SGPU_OK) return st;
+  HIP_TRY(hipSetDevice(d->device));
+  sgpu_batch* b = new sgpu_batch();
+  b->device = d->device;
+  b->nq = nq;
+  b->k_max = k_max;
+  b->max_nnz = max_nnz;
+  const uint64_t nnz = q_off[nq];
+  std::vector<uint32_t> off32(nq + 1);
+  for (uint32_t q = 0; q <= nq; ++q) off32[q] = (uint32_t)q_off[q];
+  const size_t slab = std::max<size_t>((size_t)nq * k_max, 1);
+  bool ok = hipMalloc((void**)&b->q_off, (nq + 1) * 4) == hipSuccess &&
+            hipMalloc((void**)&b->q_comp, std::max<uint64_t>(nnz, 1) * 4) == hipSuccess &&
+            hipMalloc((void**)&b->q_val, std::max<uint64_t>(nnz, 1) * 4) == hipSuccess &&
+            hipMalloc((void**)&b->out_scores, std::max<size_t>(slab, 65536) * 4) == hipSuccess &&
+            hipMalloc((void**)&b->out_ids, slab * 8) == hipSuccess &&
+            hipMalloc((void**)&b->out_n, std::max<uint32_t>(nq, 1) * 4) == hipSuccess;
+  if (!ok) {
+    batch_free(b);
+    return fail(SGPU_ENOMEM, "hipMalloc failed creating a query batch");
+  }
+  ok = hipMemcpy(b->q_off, off32.data(), (nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+       (nnz == 0 || (hipMemcpy(b->q_comp, comps, nnz * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                     hipMemcpy(b->q_val, vals, nnz * 4, hipMemcpyHostToDevice) == hipSuccess));
+  if (!ok) {
+    batch_free(b);
+    return fail(SGPU_EDEVICE, "hipMemcpy of the query batch failed");
+  }
+  *out = b;
+  return SGPU_OK;
+}
+
+static inline uint32_t up16(uint32_t x) { return (x + 15u) & ~15u; }
+
+// Chooses block size, LDS layout and grid for one search pass.
+static sgpu_status configure(DeviceIndex* d, const sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode,
+                             LaunchArgs* a) {
+  if (sp.k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
+  if (sp.k > b->k_max) return fail(SGPU_EINVAL, "k = %u exceeds the batch's k_max = %u", sp.k, b->k_max);
+  if (sp.n_knn != 0) return fail(SGPU_EINVAL, "n_knn must be 0: no kNN graph on this path");
+  if (std::isnan(sp.heap_factor)) return fail(SGPU_EINVAL, "heap_factor is NaN");
+  const uint32_t NT = env_u32("SGPU_BLOCK", 512);
+  if (NT != 256 && NT != 512 && NT != 1024) return fail(SGPU_EINVAL, "SGPU_BLOCK must be 256, 512 or 1024");
+  const uint32_t qn = std::max<uint32_t>(4, (b->max_nnz + 3u) & ~3u);
+  const uint32_t qc = std::max<uint32_t>(1, std::min<uint32_t>(mode == MODE_DOTS ? 1u : sp.query_cut, qn));
+  const uint32_t words = (d->view.dim + 31) / 32;
+  const uint32_t items_max = env_u32("SGPU_ITEMS_MAX", 1024);
+  const uint32_t top = (uint32_t)d->nb_sorted_prefix.size() - 1;
+  uint32_t dots_cap = qc <= top ? d->nb_sorted_prefix[qc]
+                                : d->nb_sorted_prefix[top] + (qc - top) * (top ? d->nb_sorted_prefix[top] - d->nb_sorted_prefix[top - 1] : 0);
+  dots_cap = std::max<uint32_t>(dots_cap, 1);
+  LdsLayout L{};
+  uint32_t o = 0;
+  L.q_comp = o; o += up16(qn * 4);
+  L.q_val = o; o += up16(qn * 4);
+  L.q_bits = o; o += up16(words * 4);
+  L.q_rank = o; o += up16(words * 2);
+  L.sel = o; o += up16((6 * qc + 1) * 4);
+  L.rt_start = o; o += up16(qc * qn * 4);
+  L.rt_pre = o; o += up16(qc * (qn + 1) * 4);
+  L.dots = o; o += up16(dots_cap * 4);
+  L.order = o; o += up16((sp.first_sorted && mode == MODE_SEARCH) ? d->max_nb * 2 : 0);
+  L.part = o; o += up16((NT / 64 + 1) * 4);
+  L.st = o; o += up16(8 * 4);
+  L.uni = o;
+  const uint32_t chunk_bytes = items_max * 14 + NT * 12;
+  uint32_t sort_bytes = 0;
+  if (sp.first_sorted && mode == MODE_SEARCH && d->max_nb > 1) {
+    uint32_t n2 = 1;
+    while (n2 < d->max_nb) n2 <<= 1;
+    sort_bytes = n2 * 8;
+  }
+  const uint32_t lds_limit = std::min<uint32_t>(d->max_lds ? d->max_lds : 65536, 160 * 1024);
+  const uint32_t target = env_u32("SGPU_LDS_TARGET", 80 * 1024);   // 2 workgroups per CU
+  uint32_t stage_bytes = env_u32("SGPU_STAGE_BYTES", 0);
+  if (!stage_bytes) {
+    stage_bytes = target > o + 8192 ? target - o : 8192;
+    stage_bytes = std::min<uint32_t>(stage_bytes, 64 * 1024);
+  }
+  stage_bytes = std::max<uint32_t>(stage_bytes, qc * 64 * 8);
+  const uint32_t uni = up16(std::max(std::max(chunk_bytes, sort_bytes), stage_bytes));
+  o += uni;
+  L.qc = qc;
+  L.qn = qn;
+  L.total = o;
+  if (o > lds_limit)
+    return fail(SGPU_ELIMIT,
+                "query needs %u bytes of LDS (dots %u blocks, %u-word bitmap, sort %u B) > %u available; "
+                "lower query_cut / use first_sorted=0 / rebuild with a smaller centroid_fraction",
+                o, dots_cap, words, sort_bytes, lds_limit);
+  a->L = L;
+  a->p.k = sp.k;
+  a->p.query_cut = qc;
+  a->p.heap_factor = sp.heap_factor;
+  a->p.first_sorted = sp.first_sorted != 0;
+  a->p.mode = mode;
+  a->p.stage_cap = uni / 8;
+  a->p.items_max = items_max;
+  a->p.items_init = std::min<uint32_t>(items_max, env_u32("SGPU_ITEMS_INIT", 128));
+  a->p.rblocks_max = env_u32("SGPU_RBLOCKS", 8);
+  a->p.target_list = mode == MODE_DOTS ? sp.query_cut : 0;
+  a->ix = d->view;
+  a->comp_width = d->comp_width;
+  a->block = NT;
+  a->lds_bytes = o;
+  a->stream = d->stream;
+  a->qb.q_off = b->q_off;
+  a->qb.q_comp = b->q_comp;
+  a->qb.q_val = b->q_val;
+  a->qb.nq = b->nq;
+  a->qb.k_stride = b->k_max;
+  a->qb.out_scores = b->out_scores;
+  a->qb.out_ids = b->out_ids;
+  a->qb.out_n = b->out_n;
+  int per_cu = 0;
+  HIP_TRY(occupancy_search(*a, &per_cu));
+  if (per_cu < 1) return fail(SGPU_ELIMIT, "the search kernel does not fit on a CU with %u bytes of LDS", o);
+  const uint32_t cap = env_u32("SGPU_WG_PER_CU", 0);
+  if (cap && (uint32_t)per_cu > cap) per_cu = (int)cap;
+  uint32_t grid = d->n_cu * (uint32_t)per_cu;
+  grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
+  a->grid = grid;
+  // visited bitmaps: one per resident workgroup
+  if (d->bitmaps_slots < grid) {
+    if (d->bitmaps) (void)hipFree(d->bitmaps);
+    d->bitmaps = nullptr;
+    d->bitmaps_slots = 0;
+    const uint32_t slots = std::max<uint32_t>(grid, d->n_cu * (uint32_t)per_cu);
+    const size_t bytes = (size_t)slots * std::max<uint32_t>(d->view.n_bitmap_words, 1) * 4;
+    if (hipMalloc((void**)&d->bitmaps, bytes) != hipSuccess)
+      return fail(SGPU_ENOMEM, "hipMalloc of %zu bytes of visited bitmaps failed", bytes);
+    HIP_TRY(hipMemsetAsync(d->bitmaps, 0, bytes, d->stream));
+    d->bitmaps_slots = slots;
+  }
+  a->queue = d->queue;
+  a->bitmaps = d->bitmaps;
+  return SGPU_OK;
+}
+
+static void drain_events(DeviceIndex* d) {   // stream must be idle
+  for (int i = 0; i < d->ev_pending; ++i) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, d->ev0[i], d->ev1[i]) == hipSuccess) {
+      d->sum_ms += ms;
+      d->n_timed += 1;
+    }
+  }
+  d->ev_pending = 0;
+}
+
+sgpu_status batch_run(DeviceIndex* d, sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode, int sync,
+                      sgpu_launch_stats* stats) {
+  if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
+  if (!b || b->device != d->device) return fail(SGPU_EINVAL, "batch does not belong to this index's device");
+  std::lock_guard<std::mutex> lock(d->mu);
+  HIP_TRY(hipSetDevice(d->device));
+  if (b->nq == 0) {
+    if (stats) *stats = sgpu_launch_stats{};
+    return SGPU_OK;
+  }
+  LaunchArgs a{};
+  sgpu_status st = configure(d, b, sp, mode, &a);
+  if (st != SGPU_OK) return st;
+  if (d->ev_pending == DeviceIndex::kEvents) {
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    drain_events(d);
+  }
+  HIP_TRY(hipMemsetAsync(d->queue, 0, 4, d->stream));
+  const int e = d->ev_pending++;
+  HIP_TRY(hipEventRecord(d->ev0[e], d->stream));
+  HIP_TRY(launch_search(a));
+  HIP_TRY(hipEventRecord(d->ev1[e], d->stream));
+  d->last.n_queries = b->nq;
+  d->last.grid = a.grid;
+  d->last.block = a.block;
+  d->last.lds_bytes = a.lds_bytes;
+  if (sync) {
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, d->ev0[e], d->ev1[e]));
+    drain_events(d);
+    d->last.kernel_ms = ms;
+    if (stats) *stats = d->last;
+  }
+  return SGPU_OK;
+}
+
+// Waits for everything enqueued; stats->kernel_ms = mean kernel duration since the last sync.
+sgpu_status batch_sync(DeviceIndex* d, sgpu_launch_stats* stats) {
+  if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device");
+  std::lock_guard<std::mutex> lock(d->mu);
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  drain_events(d);
+  if (stats) {
+    *stats = d->last;
+    stats->kernel_ms = d->n_timed ? (float)(d->sum_ms / d->n_timed) : 0.0f;
+  }
+  d->sum_ms = 0;
+  d->n_timed = 0;
+  return SGPU_OK;
+}
+
+sgpu_status batch_fetch(DeviceIndex* d, sgpu_batch* b, uint32_t k, float* out_scores, uint64_t* out_ids,
+                        uint32_t* out_n) {
+  if (!d || !b) return fail(SGPU_EINVAL, "null index/batch");
+  if (k == 0 || k > b->k_max) return fail(SGPU_EINVAL, "k out of range for this batch");
+  std::lock_guard<std::mutex> lock(d->mu);
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  if (b->nq == 0) return SGPU_OK;
+  HIP_TRY(hipMemcpy2D(out_scores, (size_t)k * 4, b->out_scores, (size_t)b->k_max * 4, (size_t)k * 4, b->nq,
+                      hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(out_ids, (size_t)k * 8, b->out_ids, (size_t)b->k_max * 8, (size_t)k * 8, b->nq,
+                      hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out_n, b->out_n, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
+  return SGPU_OK;
+}
+
+// sgpu_summary_distances: one-query batch in MODE_DOTS; dots come back through out_scores.
+sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list, const uint32_t* comps,
+                              const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb) {
+  if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
+  if (list >= h.dim) return fail(SGPU_EINVAL, "list %u >= dim", list);
+  const uint32_t nb = (uint32_t)(h.list_block_start[list + 1] - h.list_block_start[list]);
+  *out_nb = nb;
+  if (nb == 0 || nnz == 0) {
+    for (uint32_t i = 0; i < nb; ++i) out_dots[i] = 0.0f;
+    return SGPU_OK;
+  }
+  // MODE_DOTS runs stages 0-1 of the search kernel for one query, aimed at `list`
+  // (KParams::target_list, carried here in query_cut), and dumps the accumulators.
+  const uint64_t q_off[2] = {0, nnz};
+  sgpu_batch* b = nullptr;
+  sgpu_status st = batch_create(d, h.dim, q_off, comps, vals, 1, 1, &b);
+  if (st != SGPU_OK) return st;
+  sgpu_search_params sp{};
+  sp.k = 1;
+  sp.query_cut = list;   // MODE_DOTS: carries the target list id
+  sp.heap_factor = 0;
+  st = batch_run(d, b, sp, MODE_DOTS, 1, nullptr);
+  if (st == SGPU_OK) {
+    std::lock_guard<std::mutex> lock(d->mu);
+    if (hipMemcpy(out_dots, b->out_scores, (size_t)nb * 4, hipMemcpyDeviceToHost) != hipSuccess)
+      st = fail(SGPU_EDEVICE, "hipMemcpy of summary dots failed");
+  }
+  batch_free(b);
+  return st;
+}
+
+}  // namespace sgpu

@@ -1,0 +1,71 @@
+// device_types.hpp — plain structs shared by the kernel and its host-side launcher.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace sgpu {
+
+// The index as it lies in HBM (SoA; see DESIGN.md "Data layout in HBM").
+struct DevView {
+  const uint8_t* fwd;                 // document records, 16-byte aligned:
+                                      //   [npad components][npad binary16 values], npad = len rounded up to 8
+  const uint32_t* list_block_start;   // dim + 1
+  const uint32_t* block_post_start;   // n_blocks + 1
+  const uint64_t* post_ref;           // n_postings: (record offset / 16) << 16 | len
+                                      //   (the reference's PackedPostingBlock, src/posting_list.rs:32-60)
+  const uint32_t* post_doc;           // n_postings: document id (visited set key, result id)
+  const float2* blk_mq;               // n_blocks: (minimum, quant) of the block's summary
+  const uint32_t* list_row_start;     // dim + 1
+  const void* row_comp;               // n_rows, ascending within a list
+  const uint32_t* row_ptr;            // n_rows + 1
+  const uint16_t* sum_bid;            // n_entries: list-local block id
+  const uint8_t* sum_code;            // n_entries: u8 code
+  uint32_t dim, n_docs, n_bitmap_words;
+};
+
+struct BatchView {
+  const uint32_t* q_off;   // nq + 1
+  const uint32_t* q_comp;
+  const float* q_val;
+  uint32_t nq;
+  uint32_t k_stride;       // row stride of the result slabs
+  float* out_scores;
+  uint64_t* out_ids;
+  uint32_t* out_n;
+};
+
+enum { MODE_SEARCH = 0, MODE_DOTS = 1 };
+
+struct KParams {
+  uint32_t k, query_cut;
+  float heap_factor;
+  int32_t first_sorted;
+  uint32_t mode;
+  uint32_t stage_cap;    // staging entries (8 B each) available in the union region
+  uint32_t items_max;    // speculative documents per round (LDS item table)
+  uint32_t items_init;   // first round's budget; doubles every round
+  uint32_t rblocks_max;  // blocks filtered per thread and round
+  uint32_t target_list;  // MODE_DOTS: the posting list whose summary dots are wanted
+};
+
+struct LdsLayout {   // byte offsets into dynamic LDS, all multiples of 16
+  uint32_t q_comp, q_val, q_bits, q_rank, sel, rt_start, rt_pre, dots, order, uni, part, st;
+  uint32_t qc, qn;   // capacities: lists per query, components per query
+  uint32_t total;
+};
+
+struct LaunchArgs {
+  DevView ix;
+  BatchView qb;
+  KParams p;
+  LdsLayout L;
+  uint32_t* queue;
+  uint32_t* bitmaps;
+  uint32_t comp_width, grid, block, lds_bytes;
+  hipStream_t stream;
+};
+
+hipError_t launch_search(const LaunchArgs& a);
+
+}  // namespace sgpu

@@ -1,0 +1,105 @@
+// exact.cpp — exact top-k over ALL documents (ground truth for recall@k).
+//
+// Semantics of SeismicDataset.search / vectorium FlatIndex (reference
+// src/inverted_index_wrapper.rs:721-742): score every document by the inner
+// product, return the k best. Implemented as term-at-a-time accumulation over a
+// full (unpruned) inverted file of the forward index, queries in parallel on
+// the host cores. Each document's partial sums are added in ascending component
+// order (f32, no FMA), i.e. the sequential left-to-right dot product. Host code;
+// not on the hot path (used by bench.py and tests to measure recall).
+#include <algorithm>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "host_index.hpp"
+
+namespace sgpu {
+
+sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const uint32_t* comps,
+                              const float* vals, uint32_t nq, uint32_t k, uint32_t num_threads,
+                              float* out_scores, uint64_t* out_ids, uint32_t* out_n) {
+  if (k == 0) return fail(SGPU_EINVAL, "k == 0");
+  const uint64_t nnz = ix.nnz();
+  for (uint64_t i = 0; i < q_off[nq]; ++i)
+    if (comps[i] >= ix.dim) return fail(SGPU_EINVAL, "query component >= dim");
+#ifdef _OPENMP
+  const int nt = num_threads ? (int)num_threads : omp_get_max_threads();
+#else
+  const int nt = 1;
+#endif
+  try {
+    // full inverted file (component -> (doc, value)), docs ascending within a list
+    std::vector<uint64_t> ptr(ix.dim + 1, 0);
+    for (uint64_t i = 0; i < nnz; ++i) ptr[ix.comp(i) + 1]++;
+    for (uint64_t c = 0; c < ix.dim; ++c) ptr[c + 1] += ptr[c];
+    std::vector<uint32_t> idoc(nnz);
+    std::vector<uint16_t> ival(nnz);
+    {
+      std::vector<uint64_t> cur(ptr.begin(), ptr.end() - 1);
+      for (uint64_t d = 0; d < ix.n_docs; ++d)
+        for (uint64_t i = ix.fwd_offsets[d]; i < ix.fwd_offsets[d + 1]; ++i) {
+          const uint64_t p = cur[ix.comp(i)]++;
+          idoc[p] = (uint32_t)d;
+          ival[p] = ix.fwd_vals[i];
+        }
+    }
+#pragma omp parallel num_threads(nt)
+    {
+      std::vector<float> acc(ix.n_docs, 0.0f);
+      std::vector<uint8_t> seen(ix.n_docs, 0);
+      std::vector<uint32_t> touched;
+      std::vector<std::pair<float, uint32_t>> cand;
+#pragma omp for schedule(dynamic, 1)
+      for (int64_t q = 0; q < (int64_t)nq; ++q) {
+        touched.clear();
+        for (uint64_t j = q_off[q]; j < q_off[q + 1]; ++j) {  // ascending component
+          const float qv = vals[j];
+          for (uint64_t p = ptr[comps[j]]; p < ptr[comps[j] + 1]; ++p) {
+            const uint32_t d = idoc[p];
+            if (!seen[d]) {
+              seen[d] = 1;
+              touched.push_back(d);
+            }
+            acc[d] = acc[d] + qv * f16_to_f32(ival[p]);
+          }
+        }
+        cand.clear();
+        for (uint32_t d : touched) cand.emplace_back(acc[d], d);
+        auto better = [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) {
+          if (a.first != b.first) return a.first > b.first;
+          return a.second < b.second;
+        };
+        size_t kk = std::min<size_t>(k, cand.size());
+        std::partial_sort(cand.begin(), cand.begin() + (long)kk, cand.end(), better);
+        // documents sharing no component score 0 and are eligible in a flat scan
+        if (kk < k || !(cand[kk - 1].first > 0.0f)) {
+          size_t added = 0;
+          for (uint32_t d = 0; d < ix.n_docs && added < k; ++d)
+            if (!seen[d]) {
+              cand.emplace_back(0.0f, d);
+              ++added;
+            }
+          kk = std::min<size_t>(k, cand.size());
+          std::partial_sort(cand.begin(), cand.begin() + (long)kk, cand.end(), better);
+        }
+        out_n[q] = (uint32_t)kk;
+        for (size_t i = 0; i < kk; ++i) {
+          out_scores[(size_t)q * k + i] = cand[i].first;
+          out_ids[(size_t)q * k + i] = cand[i].second;
+        }
+        for (uint32_t d : touched) {
+          acc[d] = 0.0f;
+          seen[d] = 0;
+        }
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of host memory in exact search");
+  }
+  return SGPU_OK;
+}
+
+}  // namespace sgpu

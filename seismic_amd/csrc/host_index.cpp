@@ -1,0 +1,194 @@
+// host_index.cpp — descriptor validation, ownership, own flat SoA file format.
+//
+// The reference persists indexes with vectorium's IndexSerializer
+// (src/pylib/mod.rs:186-221); that wire format is not in the reference tree, so
+// real *.index.seismic files cannot be read. This file defines a versioned flat
+// format of the canonical arrays instead.
+#include "host_index.hpp"
+
+#include <cerrno>
+#include <cstdlib>
+
+namespace sgpu {
+
+std::string& last_error() {
+  static thread_local std::string e;
+  return e;
+}
+
+sgpu_status fail(sgpu_status st, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return st;
+}
+
+void HostIndex::fill_desc(sgpu_index_desc* d) const {
+  std::memset(d, 0, sizeof *d);
+  d->comp_width = comp_width;
+  d->n_docs = n_docs;
+  d->dim = dim;
+  d->nnz = nnz();
+  d->n_blocks = n_blocks();
+  d->n_postings = n_postings();
+  d->n_rows = n_rows();
+  d->n_entries = n_entries();
+  d->fwd_offsets = fwd_offsets.data();
+  d->fwd_comps = fwd_comps.data();
+  d->fwd_vals = fwd_vals.data();
+  d->list_block_start = list_block_start.data();
+  d->block_post_start = block_post_start.data();
+  d->post_doc = post_doc.data();
+  d->blk_min = blk_min.data();
+  d->blk_quant = blk_quant.data();
+  d->list_row_start = list_row_start.data();
+  d->row_comp = row_comp.data();
+  d->row_ptr = row_ptr.data();
+  d->sum_bid = sum_bid.data();
+  d->sum_code = sum_code.data();
+}
+
+static bool monotone(const uint64_t* a, uint64_t n_plus_1, uint64_t last) {
+  if (a[0] != 0) return false;
+  for (uint64_t i = 1; i < n_plus_1; ++i)
+    if (a[i] < a[i - 1]) return false;
+  return a[n_plus_1 - 1] == last;
+}
+
+sgpu_status validate_desc(const sgpu_index_desc& d) {
+  if (d.comp_width != 2 && d.comp_width != 4) return fail(SGPU_EINVAL, "comp_width must be 2 or 4");
+  if (d.dim == 0) return fail(SGPU_EINVAL, "dim == 0");
+  if (d.comp_width == 2 && d.dim > 65536) return fail(SGPU_EINVAL, "dim %llu does not fit u16 components", (unsigned long long)d.dim);
+  if (d.dim > 0xffffffffull || d.n_docs > 0x7fffffffull) return fail(SGPU_EINVAL, "dim/n_docs out of range");
+  if (!d.fwd_offsets || !d.list_block_start || !d.block_post_start || !d.list_row_start || !d.row_ptr)
+    return fail(SGPU_EINVAL, "null offset array in descriptor");
+  if (!monotone(d.fwd_offsets, d.n_docs + 1, d.nnz)) return fail(SGPU_EINVAL, "fwd_offsets not monotone / nnz mismatch");
+  if (!monotone(d.list_block_start, d.dim + 1, d.n_blocks)) return fail(SGPU_EINVAL, "list_block_start not monotone / n_blocks mismatch");
+  if (!monotone(d.block_post_start, d.n_blocks + 1, d.n_postings)) return fail(SGPU_EINVAL, "block_post_start not monotone / n_postings mismatch");
+  if (!monotone(d.list_row_start, d.dim + 1, d.n_rows)) return fail(SGPU_EINVAL, "list_row_start not monotone / n_rows mismatch");
+  if (!monotone(d.row_ptr, d.n_rows + 1, d.n_entries)) return fail(SGPU_EINVAL, "row_ptr not monotone / n_entries mismatch");
+  if ((d.nnz && (!d.fwd_comps || !d.fwd_vals)) || (d.n_postings && !d.post_doc) ||
+      (d.n_blocks && (!d.blk_min || !d.blk_quant)) || (d.n_rows && !d.row_comp) ||
+      (d.n_entries && (!d.sum_bid || !d.sum_code)))
+    return fail(SGPU_EINVAL, "null data array in descriptor");
+  auto compv = [&](const void* p, uint64_t i) -> uint32_t {
+    return d.comp_width == 2 ? (uint32_t)((const uint16_t*)p)[i] : ((const uint32_t*)p)[i];
+  };
+  for (uint64_t doc = 0; doc < d.n_docs; ++doc) {
+    const uint64_t s = d.fwd_offsets[doc], e = d.fwd_offsets[doc + 1];
+    if (e - s > 65535) return fail(SGPU_EINVAL, "document %llu has more than 65535 components (16-bit length, reference src/posting_list.rs:45-48)", (unsigned long long)doc);
+    for (uint64_t i = s; i < e; ++i) {
+      const uint32_t c = compv(d.fwd_comps, i);
+      if (c >= d.dim) return fail(SGPU_EINVAL, "document component >= dim");
+      if (i > s && c <= compv(d.fwd_comps, i - 1)) return fail(SGPU_EINVAL, "document %llu components not strictly ascending", (unsigned long long)doc);
+    }
+  }
+  for (uint64_t p = 0; p < d.n_postings; ++p)
+    if (d.post_doc[p] >= d.n_docs) return fail(SGPU_EINVAL, "posting refers to doc >= n_docs");
+  for (uint64_t c = 0; c < d.dim; ++c) {
+    const uint64_t nb = d.list_block_start[c + 1] - d.list_block_start[c];
+    if (nb > 65535) return fail(SGPU_EINVAL, "list %llu has more than 65535 blocks (reference src/posting_list.rs:243-246)", (unsigned long long)c);
+    for (uint64_t r = d.list_row_start[c]; r < d.list_row_start[c + 1]; ++r) {
+      const uint32_t rc = compv(d.row_comp, r);
+      if (rc >= d.dim) return fail(SGPU_EINVAL, "summary row component >= dim");
+      if (r > d.list_row_start[c] && rc <= compv(d.row_comp, r - 1)) return fail(SGPU_EINVAL, "summary rows of list %llu not strictly ascending", (unsigned long long)c);
+      for (uint64_t e = d.row_ptr[r]; e < d.row_ptr[r + 1]; ++e) {
+        if (d.sum_bid[e] >= nb) return fail(SGPU_EINVAL, "summary entry block id out of range");
+        if (e > d.row_ptr[r] && d.sum_bid[e] <= d.sum_bid[e - 1]) return fail(SGPU_EINVAL, "summary row block ids not strictly ascending");
+      }
+    }
+  }
+  return SGPU_OK;
+}
+
+sgpu_status host_index_from_desc(const sgpu_index_desc& d, HostIndex* out) {
+  sgpu_status st = validate_desc(d);
+  if (st != SGPU_OK) return st;
+  try {
+    HostIndex& h = *out;
+    h.comp_width = d.comp_width;
+    h.n_docs = d.n_docs;
+    h.dim = d.dim;
+    h.fwd_offsets.assign(d.fwd_offsets, d.fwd_offsets + d.n_docs + 1);
+    h.fwd_comps.assign((const uint8_t*)d.fwd_comps, (const uint8_t*)d.fwd_comps + d.nnz * d.comp_width);
+    h.fwd_vals.assign(d.fwd_vals, d.fwd_vals + d.nnz);
+    h.list_block_start.assign(d.list_block_start, d.list_block_start + d.dim + 1);
+    h.block_post_start.assign(d.block_post_start, d.block_post_start + d.n_blocks + 1);
+    h.post_doc.assign(d.post_doc, d.post_doc + d.n_postings);
+    h.blk_min.assign(d.blk_min, d.blk_min + d.n_blocks);
+    h.blk_quant.assign(d.blk_quant, d.blk_quant + d.n_blocks);
+    h.list_row_start.assign(d.list_row_start, d.list_row_start + d.dim + 1);
+    h.row_comp.assign((const uint8_t*)d.row_comp, (const uint8_t*)d.row_comp + d.n_rows * d.comp_width);
+    h.row_ptr.assign(d.row_ptr, d.row_ptr + d.n_rows + 1);
+    h.sum_bid.assign(d.sum_bid, d.sum_bid + d.n_entries);
+    h.sum_code.assign(d.sum_code, d.sum_code + d.n_entries);
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of host memory copying the index descriptor");
+  }
+  return SGPU_OK;
+}
+
+// ---- file format: "SGPUIDX1", header of 10 u64, then the arrays in desc order ----
+static const char kMagic[8] = {'S', 'G', 'P', 'U', 'I', 'D', 'X', '1'};
+
+template <class T>
+static bool wr(FILE* f, const std::vector<T>& v) {
+  return v.empty() || fwrite(v.data(), sizeof(T), v.size(), f) == v.size();
+}
+template <class T>
+static bool rd(FILE* f, std::vector<T>& v, uint64_t n) {
+  v.resize(n);
+  return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+
+sgpu_status host_index_save(const HostIndex& ix, const char* path) {
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(SGPU_EIO, "cannot open %s for writing: %s", path, strerror(errno));
+  uint64_t hdr[10] = {ix.comp_width, ix.n_docs,      ix.dim,      ix.nnz(), ix.n_blocks(),
+                      ix.n_postings(), ix.n_rows(), ix.n_entries(), 0,        0};
+  bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, 8, 10, f) == 10 && wr(f, ix.fwd_offsets) &&
+            wr(f, ix.fwd_comps) && wr(f, ix.fwd_vals) && wr(f, ix.list_block_start) &&
+            wr(f, ix.block_post_start) && wr(f, ix.post_doc) && wr(f, ix.blk_min) && wr(f, ix.blk_quant) &&
+            wr(f, ix.list_row_start) && wr(f, ix.row_comp) && wr(f, ix.row_ptr) && wr(f, ix.sum_bid) &&
+            wr(f, ix.sum_code);
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) return fail(SGPU_EIO, "short write to %s", path);
+  return SGPU_OK;
+}
+
+sgpu_status host_index_load(const char* path, HostIndex* out) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(SGPU_EIO, "cannot open %s: %s", path, strerror(errno));
+  char magic[8];
+  uint64_t hdr[10];
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kMagic, 8) != 0 || fread(hdr, 8, 10, f) != 10) {
+    fclose(f);
+    return fail(SGPU_EIO, "%s is not an SGPUIDX1 index file", path);
+  }
+  HostIndex& h = *out;
+  h.comp_width = (uint32_t)hdr[0];
+  h.n_docs = hdr[1];
+  h.dim = hdr[2];
+  const uint64_t nnz = hdr[3], nb = hdr[4], np = hdr[5], nr = hdr[6], ne = hdr[7];
+  bool ok = (h.comp_width == 2 || h.comp_width == 4);
+  try {
+    ok = ok && rd(f, h.fwd_offsets, h.n_docs + 1) && rd(f, h.fwd_comps, nnz * h.comp_width) &&
+         rd(f, h.fwd_vals, nnz) && rd(f, h.list_block_start, h.dim + 1) && rd(f, h.block_post_start, nb + 1) &&
+         rd(f, h.post_doc, np) && rd(f, h.blk_min, nb) && rd(f, h.blk_quant, nb) &&
+         rd(f, h.list_row_start, h.dim + 1) && rd(f, h.row_comp, nr * h.comp_width) && rd(f, h.row_ptr, nr + 1) &&
+         rd(f, h.sum_bid, ne) && rd(f, h.sum_code, ne);
+  } catch (const std::bad_alloc&) {
+    fclose(f);
+    return fail(SGPU_ENOMEM, "out of host memory loading %s", path);
+  }
+  fclose(f);
+  if (!ok) return fail(SGPU_EIO, "truncated or corrupt index file %s", path);
+  sgpu_index_desc d;
+  h.fill_desc(&d);
+  return validate_desc(d);
+}
+
+}  // namespace sgpu

@@ -1,0 +1,64 @@
+// host_index.hpp — canonical host-side index (the arrays of sgpu_index_desc, owned).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "common.hpp"
+
+namespace sgpu {
+
+struct DeviceIndex;  // search.hip
+
+struct HostIndex {
+  uint32_t comp_width = 2;
+  uint64_t n_docs = 0, dim = 0;
+  std::vector<uint64_t> fwd_offsets;
+  std::vector<uint8_t> fwd_comps;  // nnz * comp_width bytes
+  std::vector<uint16_t> fwd_vals;
+  std::vector<uint64_t> list_block_start, block_post_start;
+  std::vector<uint32_t> post_doc;
+  std::vector<float> blk_min, blk_quant;
+  std::vector<uint64_t> list_row_start;
+  std::vector<uint8_t> row_comp;  // n_rows * comp_width bytes
+  std::vector<uint64_t> row_ptr;
+  std::vector<uint16_t> sum_bid;
+  std::vector<uint8_t> sum_code;
+
+  uint64_t nnz() const { return fwd_offsets.empty() ? 0 : fwd_offsets.back(); }
+  uint64_t n_blocks() const { return list_block_start.empty() ? 0 : list_block_start.back(); }
+  uint64_t n_postings() const { return block_post_start.empty() ? 0 : block_post_start.back(); }
+  uint64_t n_rows() const { return list_row_start.empty() ? 0 : list_row_start.back(); }
+  uint64_t n_entries() const { return row_ptr.empty() ? 0 : row_ptr.back(); }
+  inline uint32_t comp(uint64_t i) const {
+    return comp_width == 2 ? (uint32_t)((const uint16_t*)fwd_comps.data())[i]
+                           : ((const uint32_t*)fwd_comps.data())[i];
+  }
+  inline uint32_t rcomp(uint64_t i) const {
+    return comp_width == 2 ? (uint32_t)((const uint16_t*)row_comp.data())[i]
+                           : ((const uint32_t*)row_comp.data())[i];
+  }
+  void fill_desc(sgpu_index_desc* d) const;
+};
+
+// structural validation of a descriptor (monotone offsets, ids in range, sorted rows ...)
+sgpu_status validate_desc(const sgpu_index_desc& d);
+sgpu_status host_index_from_desc(const sgpu_index_desc& d, HostIndex* out);
+sgpu_status host_index_save(const HostIndex& ix, const char* path);
+sgpu_status host_index_load(const char* path, HostIndex* out);
+
+// builder.cpp
+sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim, const uint64_t* offsets,
+                             const void* comps, const float* vals, const sgpu_build_config& cfg,
+                             HostIndex* out);
+// exact.cpp
+sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const uint32_t* comps,
+                              const float* vals, uint32_t nq, uint32_t k, uint32_t num_threads,
+                              float* out_scores, uint64_t* out_ids, uint32_t* out_n);
+
+}  // namespace sgpu
+
+// the opaque handle of the C ABI
+struct sgpu_index {
+  sgpu::HostIndex host;
+  sgpu::DeviceIndex* dev = nullptr;
+};

@@ -1,0 +1,832 @@
+// search_kernel.hip — the Seismic search hot path as one persistent gfx950 kernel.
+//
+// One query per workgroup (persistent workgroups pull queries from an atomic
+// queue). Per query, following InvertedIndexBase::search (reference
+// src/inverted_index.rs:153-234):
+//
+//   stage 0  query -> LDS: sorted (component, value) pairs, a vocabulary bitmap
+//            and per-word rank so a document component is tested with one
+//            ds_read and resolved to its query weight in O(1);
+//            the query_cut heaviest components are ranked (k_largest_by,
+//            src/inverted_index.rs:187-190) -> the posting lists to walk.
+//   stage 1  hot loop A, QuantizedSummary::distances (src/quantized_summary.rs:64-160)
+//            for ALL selected lists at once (it is a pure function of the
+//            query): matching summary rows are located by binary search,
+//            their (block id, u8 code) entries are streamed HBM -> LDS by the
+//            whole workgroup, and one wavefront per list applies them row by
+//            row to f32 accumulators in LDS. A wavefront issues its DS
+//            operations in order and block ids are distinct within a row, so
+//            every accumulator receives its additions in ascending query
+//            component order with the reference's roundings
+//            ((code*quant + min) * qv, then +=; no FMA): BIT-EXACT dots.
+//   stage 2  hot loop B, PostingList::search / sort_and_search /
+//            evaluate_posting_block (src/posting_list.rs:115-215), list by list.
+//            The reference's skip test reads the LIVE k-th best score, so the
+//            set of scored documents depends on the traversal order. The
+//            threshold only ever rises, hence testing a block against an OLDER
+//            threshold can only admit more blocks. Each round therefore
+//              (a) filters the remaining blocks against the current threshold
+//                  and compacts the survivors (in traversal order),
+//              (b) expands them to postings and scores every not-yet-visited
+//                  document SPECULATIVELY: 16 lanes per document, 16-byte
+//                  loads of the doc record (components | f16 values),
+//              (c) REPLAYS the reference's sequential decisions on one
+//                  wavefront over the (block dot, doc score) table in LDS:
+//                  same skip tests with the live threshold, same heap pushes
+//                  in the same order, visited marks only for documents the
+//                  reference would have scored.
+//            The result is the reference's exact candidate set and top-k.
+//   top-k    KHeap (src/utils.rs:12-66) lives in the VGPRs of wavefront 0 as a
+//            sorted array (entry e in lane e%64, register e/64): insertion is a
+//            ballot + one lane shift, the threshold is a readlane.
+//
+// No MFMA: this is gather / scatter-add / reduce work bounded by HBM latency
+// and bandwidth. Floating point follows the reference (Rust never contracts):
+// compiled with -ffp-contract=off and written with __fmul_rn/__fadd_rn.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "device_types.hpp"
+
+namespace sgpu {
+
+#define SGPU_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------
+SGPU_DEV int32_t total_key_dev(float f) {  // Rust f32::total_cmp order
+  int32_t b = __float_as_int(f);
+  b ^= (int32_t)(((uint32_t)(b >> 31)) >> 1);
+  return b;
+}
+
+SGPU_DEV float half_bits_to_float(uint32_t h) {   // exact binary16 -> binary32 (v_cvt_f32_f16)
+  const unsigned short b = (unsigned short)h;
+  _Float16 x;
+  __builtin_memcpy(&x, &b, 2);
+  return (float)x;
+}
+
+SGPU_DEV uint32_t lane_id() { return __lane_id(); }
+
+// inclusive scan of one u32 per thread over the whole workgroup.
+// `part` points to NT/64 + 1 LDS words. Returns inclusive prefix; *total = sum.
+template <int NT>
+SGPU_DEV uint32_t wg_inclusive_scan(uint32_t v, uint32_t* part, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t y = __shfl_up(x, d);
+    if (lane >= (uint32_t)d) x += y;
+  }
+  __syncthreads();  // protect `part` from the previous use
+  if (lane == 63) part[wave] = x;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    const uint32_t pw = part[w];
+    if ((uint32_t)w < wave) base += pw;
+    tot += pw;
+  }
+  *total = tot;
+  return x + base;
+}
+
+// ---------------------------------------------------------------------------
+// LDS view
+// ---------------------------------------------------------------------------
+struct Lds {
+  uint32_t* q_comp;
+  float* q_val;
+  uint32_t* q_bits;
+  uint16_t* q_rank;
+  uint32_t* sel_comp;   // [QC] list (component) ids in traversal order
+  uint32_t* sel_nb;     // [QC] blocks in the list
+  uint32_t* sel_b0;     // [QC] first global block id
+  uint32_t* sel_doff;   // [QC+1] offset of the list's dots in `dots`
+  uint32_t* sel_r0;     // [QC] first global summary row
+  uint32_t* sel_nr;     // [QC] number of summary rows
+  uint32_t* rt_start;   // [QC*QN] global entry index of matched row (l, j)
+  uint32_t* rt_pre;     // [QC*(QN+1)] flattened prefix of matched row lengths
+  float* dots;
+  uint16_t* order;
+  uint8_t* uni;         // union region
+  uint32_t* part;       // scan partials [NT/64 + 1]
+  uint32_t* st;         // state words
+};
+enum { ST_Q = 0, ST_NLISTS = 1, ST_THR = 2, ST_HLEN = 3, ST_TMP0 = 4, ST_TMP1 = 5, ST_TMP2 = 6, ST_TMP3 = 7, ST_WORDS = 8 };
+
+SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
+  Lds l;
+  l.q_comp = (uint32_t*)(smem + L.q_comp);
+  l.q_val = (float*)(smem + L.q_val);
+  l.q_bits = (uint32_t*)(smem + L.q_bits);
+  l.q_rank = (uint16_t*)(smem + L.q_rank);
+  l.sel_comp = (uint32_t*)(smem + L.sel);
+  l.sel_nb = l.sel_comp + L.qc;
+  l.sel_b0 = l.sel_nb + L.qc;
+  l.sel_doff = l.sel_b0 + L.qc;          // qc + 1
+  l.sel_r0 = l.sel_doff + L.qc + 1;
+  l.sel_nr = l.sel_r0 + L.qc;
+  l.rt_start = (uint32_t*)(smem + L.rt_start);
+  l.rt_pre = (uint32_t*)(smem + L.rt_pre);
+  l.dots = (float*)(smem + L.dots);
+  l.order = (uint16_t*)(smem + L.order);
+  l.uni = smem + L.uni;
+  l.part = (uint32_t*)(smem + L.part);
+  l.st = (uint32_t*)(smem + L.st);
+  return l;
+}
+
+// ---------------------------------------------------------------------------
+// stage 0: query into LDS, choose the lists
+// ---------------------------------------------------------------------------
+template <int NT>
+SGPU_DEV void load_query(const Lds& s, const BatchView& qb, uint32_t q, uint32_t* nnz_out) {
+  const uint32_t o0 = qb.q_off[q], o1 = qb.q_off[q + 1];
+  const uint32_t nnz = o1 - o0;
+  for (uint32_t j = threadIdx.x; j < nnz; j += NT) {
+    const uint32_t c = qb.q_comp[o0 + j];
+    s.q_comp[j] = c;
+    s.q_val[j] = qb.q_val[o0 + j];
+    atomicOr(&s.q_bits[c >> 5], 1u << (c & 31));
+    // rank of the first query component of each vocabulary word
+    if (j == 0 || (qb.q_comp[o0 + j - 1] >> 5) != (c >> 5)) s.q_rank[c >> 5] = (uint16_t)j;
+  }
+  *nnz_out = nnz;
+}
+
+template <int NT>
+SGPU_DEV void clear_query_bits(const Lds& s, uint32_t nnz) {
+  for (uint32_t j = threadIdx.x; j < nnz; j += NT) s.q_bits[s.q_comp[j] >> 5] = 0;
+}
+
+// k_largest_by(query_cut, total_cmp) in descending order; ties: ascending component.
+template <int NT>
+SGPU_DEV void select_lists(const Lds& s, const DevView& ix, uint32_t nnz, uint32_t query_cut) {
+  const uint32_t nl = nnz < query_cut ? nnz : query_cut;
+  for (uint32_t j = threadIdx.x; j < nnz; j += NT) {
+    const int32_t kj = total_key_dev(s.q_val[j]);
+    uint32_t rank = 0;
+    for (uint32_t i = 0; i < nnz; ++i) {
+      const int32_t ki = total_key_dev(s.q_val[i]);
+      rank += (ki > kj) || (ki == kj && i < j);   // i < j  <=>  smaller component id
+    }
+    if (rank < nl) {
+      const uint32_t c = s.q_comp[j];
+      const uint32_t b0 = ix.list_block_start[c], b1 = ix.list_block_start[c + 1];
+      const uint32_t r0 = ix.list_row_start[c], r1 = ix.list_row_start[c + 1];
+      s.sel_comp[rank] = c;
+      s.sel_b0[rank] = b0;
+      s.sel_nb[rank] = b1 - b0;
+      s.sel_r0[rank] = r0;
+      s.sel_nr[rank] = r1 - r0;
+    }
+  }
+  if (threadIdx.x == 0) s.st[ST_NLISTS] = nl;
+}
+
+// ---------------------------------------------------------------------------
+// stage 1: summary dots
+// ---------------------------------------------------------------------------
+template <typename CT, int NT>
+SGPU_DEV void build_row_table(const Lds& s, const DevView& ix, uint32_t nnz, uint32_t nl, uint32_t qn) {
+  const CT* row_comp = (const CT*)ix.row_comp;
+  // one (list, query component) pair per thread: binary search the list's sorted row components
+  for (uint32_t t = threadIdx.x; t < nl * nnz; t += NT) {
+    const uint32_t l = t / nnz, j = t - l * nnz;
+    const uint32_t target = s.q_comp[j];
+    uint32_t lo = s.sel_r0[l], hi = lo + s.sel_nr[l];
+    while (lo < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      const uint32_t c = (uint32_t)row_comp[mid];
+      if (c < target) lo = mid + 1; else hi = mid;
+    }
+    uint32_t start = 0, len = 0;
+    if (lo < s.sel_r0[l] + s.sel_nr[l] && (uint32_t)row_comp[lo] == target) {
+      start = ix.row_ptr[lo];
+      len = ix.row_ptr[lo + 1] - start;
+    }
+    s.rt_start[l * qn + j] = start;
+    s.rt_pre[l * (qn + 1) + j + 1] = len;   // turned into a prefix below
+  }
+  __syncthreads();
+  // per-list prefix over the query components (wave w handles lists w, w+NW, ...)
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t l = wave; l < nl; l += NT / 64) {
+    uint32_t* pre = s.rt_pre + l * (qn + 1);
+    uint32_t carry = 0;
+    for (uint32_t j0 = 0; j0 < nnz; j0 += 64) {
+      const uint32_t j = j0 + lane;
+      uint32_t x = j < nnz ? pre[j + 1] : 0;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+      }
+      if (j < nnz) pre[j + 1] = x + carry;
+      carry += __shfl(x, 63);
+    }
+    if (lane == 0) pre[0] = 0;
+  }
+  // dots offsets (serial, tiny)
+  if (threadIdx.x == 0) {
+    uint32_t o = 0;
+    for (uint32_t l = 0; l < nl; ++l) {
+      s.sel_doff[l] = o;
+      o += s.sel_nb[l];
+    }
+    s.sel_doff[nl] = o;
+  }
+  __syncthreads();
+}
+
+// Computes dots for lists [0, nl). stage_cap = staging entries (8 bytes each) in the union region.
+// (a) copy: the whole workgroup streams the matched rows' (block id, code) entries from HBM,
+//     dequantises and multiplies ((code*quant + min) * qv -- the reference's roundings, no FMA)
+//     and parks (block id, product) in LDS. Entries are independent: full memory parallelism.
+// (b) accumulate: one wavefront per list adds the products row by row, in ascending query
+//     component order, to the list's accumulators (LDS only, in-order DS pipeline).
+template <int NT>
+SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32_t nl, uint32_t qn,
+                           uint32_t stage_cap) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr uint32_t NW = NT / 64;
+  const uint32_t total_blocks = s.sel_doff[nl];
+  for (uint32_t i = threadIdx.x; i < total_blocks; i += NT) s.dots[i] = 0.0f;
+  uint2* stage = (uint2*)s.uni;
+  const uint32_t cap_l = (stage_cap / nl) & ~63u;   // staging window per list
+  uint32_t emax = 0;
+  for (uint32_t l = 0; l < nl; ++l) {
+    const uint32_t e = s.rt_pre[l * (qn + 1) + nnz];
+    emax = e > emax ? e : emax;
+  }
+  __syncthreads();
+  for (uint32_t w0 = 0; w0 < emax; w0 += cap_l) {
+    for (uint32_t t = wave; t < nl * nnz; t += NW) {
+      const uint32_t l = t / nnz, j = t - l * nnz;
+      const uint32_t p0 = s.rt_pre[l * (qn + 1) + j], p1 = s.rt_pre[l * (qn + 1) + j + 1];
+      const uint32_t a = p0 > w0 ? p0 : w0;
+      const uint32_t b = p1 < w0 + cap_l ? p1 : w0 + cap_l;
+      if (a >= b) continue;
+      const uint32_t gstart = s.rt_start[l * qn + j];
+      const float2* mq = ix.blk_mq + s.sel_b0[l];
+      const float qv = s.q_val[j];
+      for (uint32_t f = a + lane; f < b; f += 64) {
+        const uint32_t g = gstart + (f - p0);
+        const uint32_t bid = ix.sum_bid[g];
+        const float code = (float)ix.sum_code[g];
+        const float2 m = mq[bid];   // (min, quant): 8 B per block, L2-resident for the list
+        const float prod = __fmul_rn(__fadd_rn(__fmul_rn(code, m.y), m.x), qv);
+        stage[l * cap_l + (f - w0)] = make_uint2(bid, __float_as_uint(prod));
+      }
+    }
+    __syncthreads();
+    for (uint32_t l = wave; l < nl; l += NW) {
+      float* acc = s.dots + s.sel_doff[l];
+      const uint2* src = stage + l * cap_l;
+      const uint32_t* pre = s.rt_pre + l * (qn + 1);
+      for (uint32_t j = 0; j < nnz; ++j) {
+        const uint32_t p0 = pre[j], p1 = pre[j + 1];
+        const uint32_t a = p0 > w0 ? p0 : w0;
+        const uint32_t b = p1 < w0 + cap_l ? p1 : w0 + cap_l;
+        // block ids are distinct within a row, so lanes never collide; rows are applied
+        // in order and a wavefront's DS operations execute in issue order.
+        for (uint32_t f = a + lane; f < b; f += 64) {
+          const uint2 e = src[f - w0];
+          acc[e.x] = __fadd_rn(acc[e.x], __uint_as_float(e.y));
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// descending sort of list 0's blocks by (total_cmp(dot) desc, block id asc) -> s.order
+template <int NT>
+SGPU_DEV void sort_first_list(const Lds& s, uint32_t nb) {
+  uint64_t* keys = (uint64_t*)s.uni;
+  uint32_t n2 = 1;
+  while (n2 < nb) n2 <<= 1;
+  for (uint32_t i = threadIdx.x; i < n2; i += NT) {
+    uint64_t k = ~0ull;
+    if (i < nb) {
+      // ascending u64 order == (dot descending, block ascending)
+      const uint32_t uk = (uint32_t)total_key_dev(s.dots[i]) ^ 0x80000000u;   // monotone unsigned
+      k = ((uint64_t)(~uk) << 32) | i;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  for (uint32_t size = 2; size <= n2; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = threadIdx.x; t < n2 / 2; t += NT) {
+        const uint32_t i = 2 * t - (t & (stride - 1));
+        const uint32_t j = i + stride;
+        const bool up = (i & size) == 0;
+        const uint64_t a = keys[i], b = keys[j];
+        if ((a > b) == up) {
+          keys[i] = b;
+          keys[j] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (uint32_t i = threadIdx.x; i < nb; i += NT) s.order[i] = (uint16_t)(keys[i] & 0xffffu);
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// top-k heap in the registers of wavefront 0 (KHeap, src/utils.rs:12-66)
+// ---------------------------------------------------------------------------
+template <int KR>
+struct RegHeap {
+  float sc[KR];
+  uint32_t doc[KR];
+  uint32_t len;   // wave-uniform
+  SGPU_DEV void reset() {
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      sc[r] = -__builtin_inff();
+      doc[r] = 0xffffffffu;
+    }
+    len = 0;
+  }
+  // x (wave-uniform) is inserted at its rank; entries at index >= k are dropped.
+  SGPU_DEV void insert(float xs, uint32_t xd, uint32_t k) {
+    const uint32_t lane = lane_id();
+    uint32_t pos = 0;
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      const bool better = (sc[r] > xs) || (sc[r] == xs && doc[r] < xd);
+      pos += (uint32_t)__popcll(__ballot(better));
+    }
+#pragma unroll
+    for (int r = KR - 1; r >= 0; --r) {
+      float ps = __shfl_up(sc[r], 1);
+      uint32_t pd = __shfl_up(doc[r], 1);
+      if (r > 0) {
+        const float cs = __shfl(sc[r - 1], 63);
+        const uint32_t cd = __shfl(doc[r - 1], 63);
+        if (lane == 0) {
+          ps = cs;
+          pd = cd;
+        }
+      }
+      const uint32_t e = (uint32_t)r * 64u + lane;
+      if (e == pos) {
+        sc[r] = xs;
+        doc[r] = xd;
+      } else if (e > pos) {
+        sc[r] = ps;
+        doc[r] = pd;
+      }
+      if (e >= k) {
+        sc[r] = -__builtin_inff();
+        doc[r] = 0xffffffffu;
+      }
+    }
+    if (len < k) ++len;
+  }
+  SGPU_DEV float kth(uint32_t k) const {   // score of entry k-1 (valid when len == k)
+    float v = 0.0f;
+#pragma unroll
+    for (int r = 0; r < KR; ++r) {
+      const float x = __shfl(sc[r], (int)((k - 1) & 63));
+      if ((uint32_t)r == ((k - 1) >> 6)) v = x;
+    }
+    return v;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// stage 2 pieces
+// ---------------------------------------------------------------------------
+struct ChunkBufs {   // carved from the union region
+  uint16_t* live_pos;   // [NT] positions (in traversal order) of live blocks
+  uint32_t* cb_incl;    // [NT] inclusive item prefix
+  uint32_t* cb_p0;      // [NT] first posting of the block
+  uint16_t* cb_blk;     // [NT] block id (list-local)
+  uint64_t* it_ref;     // [ITEMS] packed doc record ref; low 32 bits reused for the score
+  uint32_t* it_doc;     // [ITEMS] doc id | (already visited) << 31
+  uint16_t* it_blk;     // [ITEMS]
+};
+
+template <int NT>
+SGPU_DEV ChunkBufs carve_chunk(uint8_t* uni, uint32_t items_max) {
+  ChunkBufs c;
+  uint8_t* p = uni;
+  c.it_ref = (uint64_t*)p;  p += (size_t)items_max * 8;
+  c.it_doc = (uint32_t*)p;  p += (size_t)items_max * 4;
+  c.cb_incl = (uint32_t*)p; p += NT * 4;
+  c.cb_p0 = (uint32_t*)p;   p += NT * 4;
+  c.it_blk = (uint16_t*)p;  p += (size_t)items_max * 2;
+  c.live_pos = (uint16_t*)p; p += NT * 2;
+  c.cb_blk = (uint16_t*)p;
+  return c;
+}
+
+SGPU_DEV bool visited_test(const uint32_t* bitmap, uint32_t doc) {
+  // written by other waves of this workgroup through L2 atomics: read past the (per-CU,
+  // not atomically updated) L1 with an agent-scope load
+  const uint32_t w = __hip_atomic_load(bitmap + (doc >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (w >> (doc & 31)) & 1u;
+}
+SGPU_DEV void visited_mark(uint32_t* bitmap, uint32_t doc) {
+  __hip_atomic_fetch_or(bitmap + (doc >> 5), 1u << (doc & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// QueryEvaluator::compute_distance for one document by one 16-lane group.
+// Canonical order: lane j accumulates elements [128 s + 8 j, +8) in
+// increasing index, then t[j] += t[j ^ d] for d = 8, 4, 2, 1.
+template <typename CT>
+SGPU_DEV float score_document(const Lds& s, const uint8_t* fwd, uint64_t ref, uint32_t sub) {
+  const uint32_t len = (uint32_t)(ref & 0xffffu);
+  const uint32_t npad = (len + 7u) & ~7u;
+  const uint8_t* rec = fwd + (ref >> 16) * 16ull;
+  const uint8_t* vals = rec + (size_t)npad * sizeof(CT);
+  float acc = 0.0f;
+  for (uint32_t e0 = sub * 8u; e0 < len; e0 += 128u) {
+    uint32_t c[8];
+    if (sizeof(CT) == 2) {
+      const uint4 cw = *(const uint4*)(rec + (size_t)e0 * 2);
+      c[0] = cw.x & 0xffffu; c[1] = cw.x >> 16; c[2] = cw.y & 0xffffu; c[3] = cw.y >> 16;
+      c[4] = cw.z & 0xffffu; c[5] = cw.z >> 16; c[6] = cw.w & 0xffffu; c[7] = cw.w >> 16;
+    } else {
+      const uint4 c0 = *(const uint4*)(rec + (size_t)e0 * 4);
+      const uint4 c1 = *(const uint4*)(rec + (size_t)e0 * 4 + 16);
+      c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
+      c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
+    }
+    const uint4 vw = *(const uint4*)(vals + (size_t)e0 * 2);
+    const uint32_t v[4] = {vw.x, vw.y, vw.z, vw.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (e0 + (uint32_t)i < len) {
+        const uint32_t comp = c[i];
+        const uint32_t w = s.q_bits[comp >> 5];
+        const uint32_t bit = comp & 31u;
+        if ((w >> bit) & 1u) {
+          const uint32_t r = (uint32_t)s.q_rank[comp >> 5] + (uint32_t)__popc(w & ((1u << bit) - 1u));
+          const float dv = half_bits_to_float((v[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
+          acc = __fadd_rn(acc, __fmul_rn(s.q_val[r], dv));
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 8; d >= 1; d >>= 1) acc = __fadd_rn(acc, __shfl_xor(acc, d, 16));
+  return acc;
+}
+
+// Sequential replay of the reference's decisions over the chunk's items (wavefront 0 only).
+template <int KR>
+SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, const float* dots, uint32_t n_items,
+                           uint32_t k, float heap_factor, uint32_t* bitmap, uint32_t& decided_blk) {
+  const uint32_t lane = lane_id();
+  const float* it_score = (const float*)cb.it_ref;   // low word of each 8-byte slot
+  uint32_t i = 0;
+  while (i < n_items) {
+    const uint32_t idx = i + lane;
+    const bool valid = idx < n_items;
+    float sc = 0.0f;
+    uint32_t doc = 0, blk = 0;
+    bool vis = true;
+    if (valid) {
+      sc = it_score[2 * idx];
+      const uint32_t d = cb.it_doc[idx];
+      doc = d & 0x7fffffffu;
+      vis = (d >> 31) != 0;
+      blk = cb.it_blk[idx];
+    }
+    if (heap.len < k) {
+      // heap not full: every block that starts now is evaluated, every new doc is pushed
+      const uint64_t nvm = __ballot(valid && !vis);
+      const uint32_t need = k - heap.len;
+      const uint32_t before = (uint32_t)__popcll(nvm & ((1ull << lane) - 1ull));
+      const bool take = valid && !vis && before < need;
+      const uint64_t tm = __ballot(take);
+      uint32_t last;   // window position of the last item consumed in this step
+      if ((uint32_t)__popcll(nvm) >= need) last = 63u - (uint32_t)__clzll(tm);
+      else last = (n_items - i < 64u ? n_items - i : 64u) - 1u;
+      if (take) visited_mark(bitmap, doc);
+      // push the taken items one by one (k is small while filling)
+      uint64_t m = tm;
+      while (m) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        heap.insert(__shfl(sc, l), __shfl(doc, l), k);
+      }
+      decided_blk = __shfl(blk, (int)last);
+      i += last + 1;
+      continue;
+    }
+    const float thr = heap.kth(k);
+    const float cut = __fmul_rn(heap_factor, thr);
+    const bool live = valid && ((blk == decided_blk) || !(dots[blk] < cut));
+    const bool changing = live && !vis && (sc > thr);
+    const uint64_t cm = __ballot(changing);
+    if (cm == 0) {
+      if (live && !vis) visited_mark(bitmap, doc);
+      i += 64;
+      continue;
+    }
+    const int f = __ffsll((long long)cm) - 1;
+    if (live && !vis && lane <= (uint32_t)f) visited_mark(bitmap, doc);
+    heap.insert(__shfl(sc, f), __shfl(doc, f), k);
+    decided_blk = __shfl(blk, f);
+    i += (uint32_t)f + 1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------
+template <typename CT, int NT, int KR>
+__global__ __launch_bounds__(NT) void seismic_search_kernel(DevView ix, BatchView qb, KParams p,
+                                                           LdsLayout L, uint32_t* queue,
+                                                           uint32_t* bitmaps) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const Lds s = carve(smem, L);
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t* bitmap = bitmaps + (size_t)blockIdx.x * ix.n_bitmap_words;
+  const ChunkBufs cb = carve_chunk<NT>(s.uni, p.items_max);
+  RegHeap<KR> heap;   // meaningful in wavefront 0
+
+  // one-time LDS init
+  for (uint32_t i = threadIdx.x; i < (ix.dim + 31) / 32; i += NT) s.q_bits[i] = 0;
+  __syncthreads();
+
+  for (;;) {
+    if (threadIdx.x == 0) s.st[ST_Q] = atomicAdd(queue, 1u);
+    __syncthreads();
+    const uint32_t q = s.st[ST_Q];
+    if (q >= qb.nq) break;
+
+    // ---- stage 0 ----
+    uint32_t nnz;
+    load_query<NT>(s, qb, q, &nnz);
+    heap.reset();
+    if (threadIdx.x == 0) {
+      s.st[ST_HLEN] = 0;
+      s.st[ST_THR] = 0;
+    }
+    __syncthreads();
+    if (p.mode == MODE_DOTS) {   // sgpu_summary_distances: aim stage 1 at one given list
+      if (threadIdx.x == 0) {
+        const uint32_t c = p.target_list;
+        s.sel_comp[0] = c;
+        s.sel_b0[0] = ix.list_block_start[c];
+        s.sel_nb[0] = ix.list_block_start[c + 1] - ix.list_block_start[c];
+        s.sel_r0[0] = ix.list_row_start[c];
+        s.sel_nr[0] = ix.list_row_start[c + 1] - ix.list_row_start[c];
+        s.st[ST_NLISTS] = nnz ? 1u : 0u;
+      }
+    } else {
+      select_lists<NT>(s, ix, nnz, p.query_cut);
+    }
+    __syncthreads();
+    const uint32_t nl = s.st[ST_NLISTS];
+
+    if (nl > 0) {
+      // ---- stage 1 ----
+      build_row_table<CT, NT>(s, ix, nnz, nl, L.qn);
+      summary_dots<NT>(s, ix, nnz, nl, L.qn, p.stage_cap);
+
+      if (p.mode == MODE_DOTS) {   // sgpu_summary_distances: dump the dots of list 0
+        for (uint32_t i = threadIdx.x; i < s.sel_nb[0]; i += NT) qb.out_scores[i] = s.dots[i];
+        if (threadIdx.x == 0) qb.out_n[q] = s.sel_nb[0];
+        __syncthreads();
+        clear_query_bits<NT>(s, nnz);
+        __syncthreads();
+        continue;
+      }
+
+      // ---- stage 2 ----
+      uint32_t budget = p.items_init;
+      for (uint32_t l = 0; l < nl; ++l) {
+        const uint32_t nb = s.sel_nb[l];
+        const uint32_t b0 = s.sel_b0[l];
+        const float* dots = s.dots + s.sel_doff[l];
+        const bool sorted = (l == 0) && p.first_sorted && nb > 1;
+        if (sorted) sort_first_list<NT>(s, nb);
+        uint32_t decided_blk = 0xffffffffu;   // wavefront 0 state
+        uint32_t pos = 0;
+        while (pos < nb) {
+          // (a) filter the remaining blocks against the current threshold
+          const uint32_t hlen = s.st[ST_HLEN];
+          const bool full = hlen == p.k;
+          const float cut = __fmul_rn(p.heap_factor, __uint_as_float(s.st[ST_THR]));
+          const uint32_t remaining = nb - pos;
+          uint32_t R = (remaining + NT - 1) / NT;
+          if (R > p.rblocks_max) R = p.rblocks_max;
+          const uint32_t scan_end = (pos + R * NT < nb) ? pos + R * NT : nb;
+          uint32_t my_live = 0;
+          const uint32_t my0 = pos + threadIdx.x * R;
+          for (uint32_t r = 0; r < R; ++r) {
+            const uint32_t idx = my0 + r;
+            if (idx < scan_end) {
+              const uint32_t b = sorted ? (uint32_t)s.order[idx] : idx;
+              my_live += !(full && dots[b] < cut);
+            }
+          }
+          uint32_t n_live_total;
+          const uint32_t live_incl = wg_inclusive_scan<NT>(my_live, s.part, &n_live_total);
+          if (n_live_total == 0) {
+            pos = scan_end;
+            continue;
+          }
+          {
+            uint32_t o = live_incl - my_live;
+            for (uint32_t r = 0; r < R && o < NT; ++r) {
+              const uint32_t idx = my0 + r;
+              if (idx < scan_end) {
+                const uint32_t b = sorted ? (uint32_t)s.order[idx] : idx;
+                if (!(full && dots[b] < cut)) cb.live_pos[o++] = (uint16_t)idx;
+              }
+            }
+          }
+          const uint32_t n_live = n_live_total < NT ? n_live_total : NT;
+          __syncthreads();
+          // (b) postings of the live blocks, budget cut
+          uint32_t cnt = 0, p0 = 0, myb = 0;
+          if (threadIdx.x < n_live) {
+            const uint32_t idx = cb.live_pos[threadIdx.x];
+            myb = sorted ? (uint32_t)s.order[idx] : idx;
+            p0 = ix.block_post_start[b0 + myb];
+            cnt = ix.block_post_start[b0 + myb + 1] - p0;
+          }
+          uint32_t items_total;
+          const uint32_t incl = wg_inclusive_scan<NT>(cnt, s.part, &items_total);
+          if (threadIdx.x == 0) s.st[ST_TMP0] = cnt;   // size of the first live block
+          __syncthreads();
+          const uint32_t first_cnt = s.st[ST_TMP0];
+          uint32_t B = budget;
+          if (first_cnt > B) B = first_cnt;             // always make progress
+          const bool oversize = first_cnt > p.items_max;
+          if (B > p.items_max) B = p.items_max;
+          uint32_t taken = (threadIdx.x < n_live && incl <= B) ? 1u : 0u;
+          uint32_t nblk;
+          (void)wg_inclusive_scan<NT>(taken, s.part, &nblk);
+          if (threadIdx.x < n_live) {
+            cb.cb_incl[threadIdx.x] = incl;
+            cb.cb_p0[threadIdx.x] = p0;
+            cb.cb_blk[threadIdx.x] = (uint16_t)myb;
+          }
+          __syncthreads();
+          uint32_t next_pos;
+          uint32_t n_pieces = 1, piece_items = 0;
+          if (oversize) {   // one block larger than the item buffer: evaluate it in pieces
+            nblk = 1;
+            n_pieces = (first_cnt + p.items_max - 1) / p.items_max;
+          }
+          if (nblk == n_live && n_live == n_live_total) next_pos = scan_end;
+          else next_pos = (uint32_t)cb.live_pos[nblk - 1] + 1;
+
+          for (uint32_t piece = 0; piece < n_pieces; ++piece) {
+            uint32_t n_items, item0 = 0;
+            if (oversize) {
+              item0 = piece * p.items_max;
+              n_items = first_cnt - item0 < p.items_max ? first_cnt - item0 : p.items_max;
+            } else {
+              n_items = cb.cb_incl[nblk - 1];
+            }
+            piece_items = n_items;
+            // (c) phase A: posting refs + visited bits (thread per item)
+            for (uint32_t i = threadIdx.x; i < n_items; i += NT) {
+              const uint32_t gi = i + item0;
+              uint32_t lo = 0, hi = nblk;   // first block with cb_incl > gi
+              while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (cb.cb_incl[mid] <= gi) lo = mid + 1; else hi = mid;
+              }
+              const uint32_t excl = lo ? cb.cb_incl[lo - 1] : 0;
+              const uint32_t pidx = cb.cb_p0[lo] + (gi - excl);
+              const uint32_t doc = ix.post_doc[pidx];
+              const uint64_t ref = ix.post_ref[pidx];
+              const uint32_t vis = visited_test(bitmap, doc) ? 0x80000000u : 0u;
+              cb.it_ref[i] = ref;
+              cb.it_doc[i] = doc | vis;
+              cb.it_blk[i] = cb.cb_blk[lo];
+            }
+            __syncthreads();
+            // (d) phase B: speculative scoring, 16 lanes per document
+            {
+              const uint32_t grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
+              for (uint32_t i = grp; i < n_items; i += NT / 16) {
+                const uint64_t ref = cb.it_ref[i];
+                const bool vis = (cb.it_doc[i] >> 31) != 0;
+                float sc = 0.0f;
+                if (!vis) sc = score_document<CT>(s, ix.fwd, ref, sub);
+                if (sub == 0) ((float*)cb.it_ref)[2 * i] = sc;
+              }
+            }
+            __syncthreads();
+            // (e) exact replay on wavefront 0
+            if (wave == 0) {
+              replay_chunk<KR>(heap, cb, dots, n_items, p.k, p.heap_factor, bitmap, decided_blk);
+              if (lane == 0) {
+                s.st[ST_HLEN] = heap.len;
+                s.st[ST_THR] = __float_as_uint(heap.len == p.k ? heap.kth(p.k) : 0.0f);
+              }
+            }
+            __syncthreads();
+          }
+          (void)piece_items;
+          pos = next_pos;
+          budget = budget * 2 < p.items_max ? budget * 2 : p.items_max;
+        }
+      }
+    }
+
+    // ---- results: best first (into_sorted_vec, src/inverted_index.rs:227-233) ----
+    if (wave == 0) {
+      float* os = qb.out_scores + (size_t)q * qb.k_stride;
+      uint64_t* oi = qb.out_ids + (size_t)q * qb.k_stride;
+#pragma unroll
+      for (int r = 0; r < KR; ++r) {
+        const uint32_t e = (uint32_t)r * 64u + lane;
+        if (e < p.k) {
+          os[e] = e < heap.len ? heap.sc[r] : 0.0f;
+          oi[e] = e < heap.len ? (uint64_t)heap.doc[r] : ~0ull;
+        }
+      }
+      if (lane == 0) qb.out_n[q] = heap.len;
+    }
+    // ---- per-query cleanup: visited bitmap, query bits ----
+    for (uint32_t i = threadIdx.x; i < ix.n_bitmap_words; i += NT) bitmap[i] = 0;
+    clear_query_bits<NT>(s, nnz);
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host-callable launcher table
+// ---------------------------------------------------------------------------
+template <typename CT, int NT, int KR>
+static hipError_t launch_one(const LaunchArgs& a) {
+  auto kern = seismic_search_kernel<CT, NT, KR>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)a.lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(a.grid), dim3(NT), a.lds_bytes, a.stream, a.ix, a.qb, a.p, a.L, a.queue,
+                     a.bitmaps);
+  return hipGetLastError();
+}
+
+template <typename CT, int NT>
+static hipError_t launch_kr(const LaunchArgs& a) {
+  const uint32_t k = a.p.k;
+  if (k <= 64) return launch_one<CT, NT, 1>(a);
+  if (k <= 128) return launch_one<CT, NT, 2>(a);
+  if (k <= 256) return launch_one<CT, NT, 4>(a);
+  if (k <= 512) return launch_one<CT, NT, 8>(a);
+  return launch_one<CT, NT, 16>(a);
+}
+
+template <typename CT, int NT, int KR>
+static hipError_t occ_one(const LaunchArgs& a, int* n) {
+  auto kern = seismic_search_kernel<CT, NT, KR>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)a.lds_bytes);
+  if (e != hipSuccess) return e;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, kern, NT, a.lds_bytes);
+}
+template <typename CT, int NT>
+static hipError_t occ_kr(const LaunchArgs& a, int* n) {
+  const uint32_t k = a.p.k;
+  if (k <= 64) return occ_one<CT, NT, 1>(a, n);
+  if (k <= 128) return occ_one<CT, NT, 2>(a, n);
+  if (k <= 256) return occ_one<CT, NT, 4>(a, n);
+  if (k <= 512) return occ_one<CT, NT, 8>(a, n);
+  return occ_one<CT, NT, 16>(a, n);
+}
+hipError_t occupancy_search(const LaunchArgs& a, int* n) {
+  if (a.comp_width == 2) {
+    if (a.block == 256) return occ_kr<uint16_t, 256>(a, n);
+    if (a.block == 1024) return occ_kr<uint16_t, 1024>(a, n);
+    return occ_kr<uint16_t, 512>(a, n);
+  }
+  if (a.block == 256) return occ_kr<uint32_t, 256>(a, n);
+  if (a.block == 1024) return occ_kr<uint32_t, 1024>(a, n);
+  return occ_kr<uint32_t, 512>(a, n);
+}
+
+hipError_t launch_search(const LaunchArgs& a) {
+  if (a.comp_width == 2) {
+    if (a.block == 256) return launch_kr<uint16_t, 256>(a);
+    if (a.block == 1024) return launch_kr<uint16_t, 1024>(a);
+    return launch_kr<uint16_t, 512>(a);
+  }
+  if (a.block == 256) return launch_kr<uint32_t, 256>(a);
+  if (a.block == 1024) return launch_kr<uint32_t, 1024>(a);
+  return launch_kr<uint32_t, 512>(a);
+}
+
+}  // namespace sgpu

@@ -1,0 +1,201 @@
+// synth.cpp — deterministic SPLADE-shaped synthetic sparse vectors.
+//
+// There is no network for MS MARCO / SPLADE-v3 embeddings, so bench.py and the
+// full-size parity tests draw documents and queries of that SHAPE:
+//   vocabulary V, token popularity Zipf(s=1) over a seeded permutation of ids;
+//   document nnz ~ round(lognormal(ln 110, 0.35)) clipped to [16, 400] (mean ~120);
+//   values v = min(3.5, 0.02 + Exp(mean 0.45)) (toy_dataset range 0.001..2.6);
+//   topical structure: every document belongs to one of T topics and draws 70%
+//   of its tokens from that topic's 256-token set (so k-means blocks and their
+//   summaries are as discriminative as on real learned-sparse data), 30% from
+//   the global Zipf law;
+//   queries: nnz ~ clipped normal(43, 10) in [8, 96]; 60% of the tokens are the
+//   heaviest components of a random source document, 40% Zipf; values from the
+//   same law in f32, all distinct within a query (no tie ambiguity).
+// PRNG: SplitMix64 only; no std:: distributions (stable across libstdc++ builds).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+
+namespace sgpu {
+namespace {
+
+struct Zipf {
+  std::vector<double> cdf;
+  std::vector<uint32_t> perm;
+  Zipf(uint64_t dim, uint64_t seed) : cdf(dim), perm(dim) {
+    double h = 0;
+    for (uint64_t r = 0; r < dim; ++r) {
+      h += 1.0 / (double)(r + 1);
+      cdf[r] = h;
+    }
+    for (auto& x : cdf) x /= h;
+    for (uint64_t i = 0; i < dim; ++i) perm[i] = (uint32_t)i;
+    SplitMix64 rng(seed ^ 0x5eed5eedull);
+    for (uint64_t i = dim - 1; i > 0; --i) std::swap(perm[i], perm[rng.below(i + 1)]);
+  }
+  uint32_t draw(SplitMix64& rng) const {
+    const double u = rng.unit();
+    size_t r = (size_t)(std::lower_bound(cdf.begin(), cdf.end(), u) - cdf.begin());
+    if (r >= cdf.size()) r = cdf.size() - 1;
+    return perm[r];
+  }
+};
+
+inline double normal(SplitMix64& rng) {  // Box-Muller, one value
+  double u1 = rng.unit(), u2 = rng.unit();
+  if (u1 < 1e-300) u1 = 1e-300;
+  return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+}
+inline float value_law(SplitMix64& rng, double scale) {
+  double u = rng.unit();
+  if (u < 1e-300) u = 1e-300;
+  double v = 0.02 + (-std::log(u)) * 0.45 * scale;
+  return (float)std::min(3.5, v);
+}
+
+constexpr uint32_t kTopicTokens = 256;
+
+}  // namespace
+
+// Topic tables depend only on (dim, topic count), never on the stream seed, so
+// documents (seed 42) and queries (seed 43) share the same topics.
+static void make_topics(uint64_t dim, uint32_t n_topics, const Zipf& z, std::vector<uint32_t>& tok,
+                        std::vector<float>& scale) {
+  tok.resize((size_t)n_topics * kTopicTokens);
+  scale.resize(tok.size());
+  SplitMix64 rng(0x70b1c5ull ^ dim);
+  std::vector<uint8_t> used(dim, 0);
+  for (uint32_t t = 0; t < n_topics; ++t) {
+    uint32_t* tt = &tok[(size_t)t * kTopicTokens];
+    const uint32_t want = (uint32_t)std::min<uint64_t>(kTopicTokens, dim);
+    uint32_t n = 0;
+    while (n < want) {
+      // half Zipf (shared, popular), half uniform (topic-specific, rare)
+      uint32_t c = (n & 1) ? (uint32_t)rng.below(dim) : z.draw(rng);
+      if (used[c]) continue;
+      used[c] = 1;
+      tt[n] = c;
+      scale[(size_t)t * kTopicTokens + n] = (float)(0.5 + 1.5 * rng.unit());
+      ++n;
+    }
+    for (uint32_t i = 0; i < n; ++i) used[tt[i]] = 0;
+    for (uint32_t i = n; i < kTopicTokens; ++i) tt[i] = tt[i % std::max(1u, n)];
+  }
+}
+
+static inline uint64_t mix_seed(uint64_t seed, uint64_t i) {
+  SplitMix64 m(seed * 0x9e3779b97f4a7c15ull + i);
+  m.next();
+  return m.next();
+}
+
+// number of components of vector i: the first draws of its private stream
+static inline uint32_t draw_nnz(SplitMix64& rng, uint32_t kind, uint64_t dim) {
+  if (kind == 0) {
+    const double ln = std::log(110.0) + 0.35 * normal(rng);
+    uint32_t n = (uint32_t)std::llround(std::exp(ln));
+    n = std::max(16u, std::min(400u, n));
+    return (uint32_t)std::min<uint64_t>(n, dim / 2);
+  }
+  const double g = 43.0 + 10.0 * normal(rng);
+  return (uint32_t)std::llround(std::max(8.0, std::min(96.0, g)));
+}
+
+extern "C" sgpu_status sgpu_synth_generate(const sgpu_synth_spec* spec, const uint64_t* docs_offsets,
+                                           const uint32_t* docs_comps, const float* docs_vals,
+                                           uint64_t n_docs, uint64_t* out_offsets, uint32_t* out_comps,
+                                           float* out_vals, uint64_t* out_nnz) {
+  if (!spec || !out_nnz) return fail(SGPU_EINVAL, "null spec / out_nnz");
+  if (spec->dim < 1024) return fail(SGPU_EINVAL, "dim must be >= 1024");
+  if (spec->kind == 1 && (n_docs == 0 || !docs_offsets || !docs_comps || !docs_vals))
+    return fail(SGPU_EINVAL, "queries need the source documents");
+  const uint64_t dim = spec->dim;
+  const bool write = out_comps != nullptr;
+  if (write && (!out_offsets || !out_vals)) return fail(SGPU_EINVAL, "null output arrays");
+  // pass 1: sizes (every vector has its own stream, so this is cheap and the fill is parallel)
+  std::vector<uint64_t> off(spec->n_vecs + 1, 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)spec->n_vecs; ++i) {
+    SplitMix64 rng(mix_seed(spec->seed, (uint64_t)i));
+    off[(size_t)i + 1] = draw_nnz(rng, spec->kind, dim);
+  }
+  for (uint64_t i = 0; i < spec->n_vecs; ++i) off[i + 1] += off[i];
+  *out_nnz = off[spec->n_vecs];
+  if (!write) return SGPU_OK;
+  std::copy(off.begin(), off.end(), out_offsets);
+
+  Zipf z(dim, 0xd1ce);
+  const uint32_t n_topics = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(4096, dim / 64));
+  std::vector<uint32_t> ttok;
+  std::vector<float> tscale;
+  make_topics(dim, n_topics, z, ttok, tscale);
+
+#pragma omp parallel
+  {
+    std::vector<uint8_t> used(dim, 0);
+    std::vector<std::pair<uint32_t, float>> cur;
+    std::vector<std::pair<float, uint32_t>> sv;
+    std::vector<float> seen;
+#pragma omp for schedule(dynamic, 256)
+    for (int64_t ii = 0; ii < (int64_t)spec->n_vecs; ++ii) {
+      const uint64_t i = (uint64_t)ii;
+      SplitMix64 rng(mix_seed(spec->seed, i));
+      const uint32_t n = draw_nnz(rng, spec->kind, dim);
+      cur.clear();
+      if (spec->kind == 0) {
+        const uint32_t topic = (uint32_t)rng.below(n_topics);
+        const uint32_t n_topic = std::min<uint32_t>((uint32_t)(0.7 * n), kTopicTokens / 2);
+        uint32_t guard = 0;
+        while (cur.size() < n_topic && guard++ < 8 * kTopicTokens) {
+          const uint32_t j = (uint32_t)rng.below(kTopicTokens);
+          const uint32_t c = ttok[(size_t)topic * kTopicTokens + j];
+          if (used[c]) continue;
+          used[c] = 1;
+          cur.emplace_back(c, value_law(rng, tscale[(size_t)topic * kTopicTokens + j]));
+        }
+        while (cur.size() < n) {
+          const uint32_t c = z.draw(rng);
+          if (used[c]) continue;
+          used[c] = 1;
+          cur.emplace_back(c, value_law(rng, 1.0));
+        }
+      } else {
+        const uint64_t src = rng.below(n_docs);
+        const uint64_t s = docs_offsets[src], e = docs_offsets[src + 1];
+        sv.clear();
+        for (uint64_t p = s; p < e; ++p) sv.emplace_back(-docs_vals[p], docs_comps[p]);
+        std::sort(sv.begin(), sv.end());
+        const uint32_t n_src = (uint32_t)std::min<size_t>((size_t)std::llround(0.6 * n), sv.size());
+        for (uint32_t j = 0; j < n_src; ++j) {
+          used[sv[j].second] = 1;
+          cur.emplace_back(sv[j].second, value_law(rng, 1.0));
+        }
+        while (cur.size() < n) {
+          const uint32_t c = z.draw(rng);
+          if (used[c]) continue;
+          used[c] = 1;
+          cur.emplace_back(c, value_law(rng, 1.0));
+        }
+        seen.clear();  // make the values of one query pairwise distinct
+        for (auto& cv : cur) {
+          while (std::find(seen.begin(), seen.end(), cv.second) != seen.end())
+            cv.second = std::nextafterf(cv.second, 0.0f);
+          seen.push_back(cv.second);
+        }
+      }
+      std::sort(cur.begin(), cur.end());
+      for (auto& cv : cur) used[cv.first] = 0;
+      const uint64_t base = off[i];
+      for (size_t j = 0; j < cur.size(); ++j) {
+        out_comps[base + j] = cur[j].first;
+        out_vals[base + j] = cur[j].second;
+      }
+    }
+  }
+  return SGPU_OK;
+}
+
+}  // namespace sgpu
