@@ -195,6 +195,14 @@ sgpu_status sgpu_batch_run(sgpu_index* idx, sgpu_batch* batch,
 sgpu_status sgpu_batch_sync(sgpu_index* idx, sgpu_launch_stats* stats);
 sgpu_status sgpu_batch_fetch(sgpu_index* idx, sgpu_batch* batch, uint32_t k,
                              float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n);
+/* Work counters of the batch's LAST pass, nq x 24 uint32 per query:
+ *   [0] blocks of the walked lists   [1] summary rows matched   [2] summary entries read
+ *   [3] blocks that passed the skip test   [4] postings of those blocks
+ *   [5] documents scored (as the reference would)   [6] sum of their component counts
+ *   [7] documents the kernel scored speculatively (>= [5]; the surplus is overhead)
+ *   [8..19] kernel phase clocks (shader cycles / 16), [20] workgroup slot, [21..23] reserved
+ * Counters [0..6] are what the ALGORITHM touches and feed the roofline accounting. */
+sgpu_status sgpu_batch_fetch_stats(sgpu_index* idx, sgpu_batch* batch, uint32_t* out_counters);
 void sgpu_batch_destroy(sgpu_batch* batch);
 
 /* Hot loop A in isolation — replaces QuantizedSummary::distances

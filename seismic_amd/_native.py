@@ -55,6 +55,7 @@ def lib():
         L.sgpu_batch_run.argtypes = [vp, vp, C.POINTER(SearchParams), C.c_int32, C.POINTER(LaunchStats)]
         L.sgpu_batch_sync.argtypes = [vp, C.POINTER(LaunchStats)]
         L.sgpu_batch_fetch.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
+        L.sgpu_batch_fetch_stats.argtypes = [vp, vp, vp]
         L.sgpu_summary_distances.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
         L.sgpu_exact_search.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
         L.sgpu_synth_generate.argtypes = [C.POINTER(SynthSpec), vp, vp, vp, C.c_uint64, vp, vp, vp,
@@ -222,6 +223,20 @@ class DeviceBatch:
         n = np.zeros(max(self.nq, 1), np.uint32)
         check(lib().sgpu_batch_fetch(self.index.h, self.h, k, _p(sc), _p(ids), _p(n)))
         return sc, ids, n[: self.nq]
+
+    def fetch_stats(self):
+        """nq x 24 counters of the last pass (see sgpu_batch_fetch_stats)."""
+        st = np.zeros((max(self.nq, 1), 24), np.uint32)
+        check(lib().sgpu_batch_fetch_stats(self.index.h, self.h, _p(st)))
+        return st[: self.nq]
+
+    def algorithmic_bytes(self, k, comp_width):
+        """B_q of SURVEY.md 8(d), summed over the batch, from the kernel's own work counters."""
+        st = self.fetch_stats().astype(np.int64)
+        nnz_q = np.diff(self.q_off.astype(np.int64))
+        b = (nnz_q * (comp_width + 4) + 12 * k + 8 * st[:, 0] + 8 * st[:, 1] + 3 * st[:, 2]
+             + 4 * (st[:, 4] + st[:, 3]) + 8 * st[:, 5] + st[:, 6] * (comp_width + 2))
+        return int(b.sum()), st
 
     def close(self):
         if self.h:

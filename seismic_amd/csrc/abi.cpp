@@ -18,6 +18,7 @@ sgpu_status batch_run(DeviceIndex* d, sgpu_batch* b, const sgpu_search_params& s
 sgpu_status batch_sync(DeviceIndex* d, sgpu_launch_stats* stats);
 sgpu_status batch_fetch(DeviceIndex* d, sgpu_batch* b, uint32_t k, float* out_scores, uint64_t* out_ids,
                         uint32_t* out_n);
+sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out);
 sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list, const uint32_t* comps,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
 int device_count();
@@ -130,6 +131,11 @@ sgpu_status sgpu_batch_fetch(sgpu_index* idx, sgpu_batch* batch, uint32_t k, flo
                              uint64_t* out_doc_ids, uint32_t* out_n) {
   if (!idx || !batch || !out_scores || !out_doc_ids || !out_n) return fail(SGPU_EINVAL, "null argument");
   return batch_fetch(idx->dev, batch, k, out_scores, out_doc_ids, out_n);
+}
+
+sgpu_status sgpu_batch_fetch_stats(sgpu_index* idx, sgpu_batch* batch, uint32_t* out_counters) {
+  if (!idx || !batch || !out_counters) return fail(SGPU_EINVAL, "null argument");
+  return batch_fetch_stats(idx->dev, batch, out_counters);
 }
 
 void sgpu_batch_destroy(sgpu_batch* batch) { batch_free(batch); }

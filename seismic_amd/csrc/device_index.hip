@@ -30,7 +30,7 @@ struct DeviceIndex {
   uint64_t bytes = 0;
   uint32_t n_cu = 0;
   uint32_t max_lds = 0;
-  std::vector<uint32_t> nb_sorted_prefix;   // prefix sums of list block counts, largest first (<= 64)
+  std::vector<uint32_t> list_nb, list_np;   // blocks / postings per posting list (host copy)
   uint32_t max_nb = 0;
   // per-launch scratch
   uint32_t* queue = nullptr;
@@ -178,13 +178,13 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     d->view.n_docs = (uint32_t)h.n_docs;
     d->view.n_bitmap_words = (uint32_t)((h.n_docs + 31) / 32);
     // ---- block-count statistics for LDS sizing
-    std::vector<uint32_t> nbs(h.dim);
-    for (uint64_t c = 0; c < h.dim; ++c) nbs[c] = (uint32_t)(h.list_block_start[c + 1] - h.list_block_start[c]);
-    const size_t top = std::min<size_t>(64, nbs.size());
-    std::partial_sort(nbs.begin(), nbs.begin() + (long)top, nbs.end(), std::greater<uint32_t>());
-    d->nb_sorted_prefix.assign(top + 1, 0);
-    for (size_t i = 0; i < top; ++i) d->nb_sorted_prefix[i + 1] = d->nb_sorted_prefix[i] + nbs[i];
-    d->max_nb = top ? nbs[0] : 0;
+    d->list_nb.resize(h.dim);
+    d->list_np.resize(h.dim);
+    for (uint64_t c = 0; c < h.dim; ++c) {
+      d->list_nb[c] = (uint32_t)(h.list_block_start[c + 1] - h.list_block_start[c]);
+      d->list_np[c] = (uint32_t)(h.block_post_start[h.list_block_start[c + 1]] - h.block_post_start[h.list_block_start[c]]);
+      d->max_nb = std::max(d->max_nb, d->list_nb[c]);
+    }
     if (hipMalloc((void**)&d->queue, 256) != hipSuccess) return bail(fail(SGPU_ENOMEM, "hipMalloc(queue) failed"));
   } catch (const std::bad_alloc&) {
     return bail(fail(SGPU_ENOMEM, "out of host memory packing the index for upload"));
@@ -198,7 +198,18 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
 // ---------------------------------------------------------------------------
 }  // namespace sgpu
 
+struct sgpu_batch_plan {   // per (batch, query_cut): LDS need and processing order
+  uint32_t query_cut = 0;
+  uint32_t dots_cap = 1;    // max over queries of the blocks of the lists it walks
+  uint32_t max_nb = 0;      // largest single list walked first (sort buffer sizing)
+  uint32_t* d_order = nullptr;
+};
+
 struct sgpu_batch {
+  std::vector<uint64_t> h_off;
+  std::vector<uint32_t> h_comp;
+  std::vector<float> h_val;
+  std::vector<sgpu_batch_plan> plans;
   int device = -1;
   uint32_t nq = 0, k_max = 0, max_nnz = 0;
   uint32_t* q_off = nullptr;
@@ -207,6 +218,7 @@ struct sgpu_batch {
   float* out_scores = nullptr;
   uint64_t* out_ids = nullptr;
   uint32_t* out_n = nullptr;
+  uint32_t* out_stats = nullptr;   // nq x 8 work counters of the last pass
 };
 
 namespace sgpu {
@@ -249,6 +261,8 @@ void batch_free(sgpu_batch* b) {
   (void)hipFree(b->out_scores);
   (void)hipFree(b->out_ids);
   (void)hipFree(b->out_n);
+  (void)hipFree(b->out_stats);
+  for (auto& pl : b->plans) (void)hipFree(pl.d_order);
   delete b;
 }
 
@@ -267,6 +281,9 @@ sgpu_status batch_create(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, co
   b->k_max = k_max;
   b->max_nnz = max_nnz;
   const uint64_t nnz = q_off[nq];
+  b->h_off.assign(q_off, q_off + nq + 1);
+  b->h_comp.assign(comps, comps + nnz);
+  b->h_val.assign(vals, vals + nnz);
   std::vector<uint32_t> off32(nq + 1);
   for (uint32_t q = 0; q <= nq; ++q) off32[q] = (uint32_t)q_off[q];
   const size_t slab = std::max<size_t>((size_t)nq * k_max, 1);
@@ -275,7 +292,8 @@ sgpu_status batch_create(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, co
             hipMalloc((void**)&b->q_val, std::max<uint64_t>(nnz, 1) * 4) == hipSuccess &&
             hipMalloc((void**)&b->out_scores, std::max<size_t>(slab, 65536) * 4) == hipSuccess &&
             hipMalloc((void**)&b->out_ids, slab * 8) == hipSuccess &&
-            hipMalloc((void**)&b->out_n, std::max<uint32_t>(nq, 1) * 4) == hipSuccess;
+            hipMalloc((void**)&b->out_n, std::max<uint32_t>(nq, 1) * 4) == hipSuccess &&
+            hipMalloc((void**)&b->out_stats, std::max<uint32_t>(nq, 1) * STATS_WORDS * 4) == hipSuccess;
   if (!ok) {
     batch_free(b);
     return fail(SGPU_ENOMEM, "hipMalloc failed creating a query batch");
@@ -293,8 +311,52 @@ sgpu_status batch_create(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, co
 
 static inline uint32_t up16(uint32_t x) { return (x + 15u) & ~15u; }
 
+// Which lists each query will walk (the device applies the same rule: query_cut heaviest
+// components by f32::total_cmp, ties by ascending component), hence how many block dots it
+// needs in LDS, and an a-priori cost (postings of those lists) to start long queries first.
+static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, const sgpu_batch_plan** out) {
+  for (const auto& pl : b->plans)
+    if (pl.query_cut == query_cut) {
+      *out = &pl;
+      return SGPU_OK;
+    }
+  sgpu_batch_plan pl;
+  pl.query_cut = query_cut;
+  std::vector<std::pair<uint64_t, uint32_t>> cost(b->nq);
+  std::vector<std::pair<int32_t, uint32_t>> kv;
+  for (uint32_t q = 0; q < b->nq; ++q) {
+    kv.clear();
+    for (uint64_t i = b->h_off[q]; i < b->h_off[q + 1]; ++i) kv.emplace_back(total_key(b->h_val[i]), b->h_comp[i]);
+    const size_t nl = std::min<size_t>(query_cut, kv.size());
+    std::partial_sort(kv.begin(), kv.begin() + (long)nl, kv.end(),
+                      [](const std::pair<int32_t, uint32_t>& a, const std::pair<int32_t, uint32_t>& c) {
+                        if (a.first != c.first) return a.first > c.first;
+                        return a.second < c.second;
+                      });
+    uint64_t np = 0;
+    uint32_t nb = 0;
+    for (size_t i = 0; i < nl; ++i) {
+      nb += d->list_nb[kv[i].second];
+      np += d->list_np[kv[i].second];
+    }
+    if (nl) pl.max_nb = std::max(pl.max_nb, d->list_nb[kv[0].second]);
+    pl.dots_cap = std::max(pl.dots_cap, nb);
+    cost[q] = {np, q};
+  }
+  std::stable_sort(cost.begin(), cost.end(),
+                   [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) { return a.first > c.first; });
+  std::vector<uint32_t> order(b->nq);
+  for (uint32_t i = 0; i < b->nq; ++i) order[i] = cost[i].second;
+  if (hipMalloc((void**)&pl.d_order, std::max<uint32_t>(b->nq, 1) * 4) != hipSuccess)
+    return fail(SGPU_ENOMEM, "hipMalloc(q_order) failed");
+  if (b->nq) HIP_TRY(hipMemcpy(pl.d_order, order.data(), (size_t)b->nq * 4, hipMemcpyHostToDevice));
+  b->plans.push_back(pl);
+  *out = &b->plans.back();
+  return SGPU_OK;
+}
+
 // Chooses block size, LDS layout and grid for one search pass.
-static sgpu_status configure(DeviceIndex* d, const sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode,
+static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode,
                              LaunchArgs* a) {
   if (sp.k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
   if (sp.k > b->k_max) return fail(SGPU_EINVAL, "k = %u exceeds the batch's k_max = %u", sp.k, b->k_max);
@@ -306,39 +368,47 @@ static sgpu_status configure(DeviceIndex* d, const sgpu_batch* b, const sgpu_sea
   const uint32_t qc = std::max<uint32_t>(1, std::min<uint32_t>(mode == MODE_DOTS ? 1u : sp.query_cut, qn));
   const uint32_t words = (d->view.dim + 31) / 32;
   const uint32_t items_max = env_u32("SGPU_ITEMS_MAX", 1024);
-  const uint32_t top = (uint32_t)d->nb_sorted_prefix.size() - 1;
-  uint32_t dots_cap = qc <= top ? d->nb_sorted_prefix[qc]
-                                : d->nb_sorted_prefix[top] + (qc - top) * (top ? d->nb_sorted_prefix[top] - d->nb_sorted_prefix[top - 1] : 0);
-  dots_cap = std::max<uint32_t>(dots_cap, 1);
+  uint32_t dots_cap = 1, sort_nb = 0;
+  const uint32_t* d_order = nullptr;
+  if (mode == MODE_DOTS) {
+    dots_cap = std::max<uint32_t>(1, d->list_nb[sp.query_cut]);
+  } else {
+    const sgpu_batch_plan* pl = nullptr;
+    sgpu_status pst = plan_for(d, b, qc, &pl);
+    if (pst != SGPU_OK) return pst;
+    dots_cap = pl->dots_cap;
+    sort_nb = pl->max_nb;
+    d_order = env_u32("SGPU_NO_LPT", 0) ? nullptr : pl->d_order;
+  }
   LdsLayout L{};
   uint32_t o = 0;
   L.q_comp = o; o += up16(qn * 4);
-  L.q_val = o; o += up16(qn * 4);
-  L.q_bits = o; o += up16(words * 4);
-  L.q_rank = o; o += up16(words * 2);
+  L.q_val = o; o += up16((qn + 1) * 4);   // + the 0.0 slot non-matching components resolve to
+  L.q_bits = o; o += up16(words * 8);   // {bits, rank} per 32 vocabulary ids
+  L.q_rank = o;
   L.sel = o; o += up16((6 * qc + 1) * 4);
   L.rt_start = o; o += up16(qc * qn * 4);
   L.rt_pre = o; o += up16(qc * (qn + 1) * 4);
   L.dots = o; o += up16(dots_cap * 4);
-  L.order = o; o += up16((sp.first_sorted && mode == MODE_SEARCH) ? d->max_nb * 2 : 0);
+  L.order = o; o += up16((sp.first_sorted && mode == MODE_SEARCH) ? sort_nb * 2 : 0);
   L.part = o; o += up16((NT / 64 + 1) * 4);
   L.st = o; o += up16(8 * 4);
   L.uni = o;
-  const uint32_t chunk_bytes = items_max * 14 + NT * 12;
+  const uint32_t chunk_bytes = items_max * 18 + NT * 12;
   uint32_t sort_bytes = 0;
-  if (sp.first_sorted && mode == MODE_SEARCH && d->max_nb > 1) {
+  if (sp.first_sorted && mode == MODE_SEARCH && sort_nb > 1) {
     uint32_t n2 = 1;
-    while (n2 < d->max_nb) n2 <<= 1;
+    while (n2 < sort_nb) n2 <<= 1;
     sort_bytes = n2 * 8;
   }
   const uint32_t lds_limit = std::min<uint32_t>(d->max_lds ? d->max_lds : 65536, 160 * 1024);
-  const uint32_t target = env_u32("SGPU_LDS_TARGET", 80 * 1024);   // 2 workgroups per CU
+  const uint32_t target = env_u32("SGPU_LDS_TARGET", 76 * 1024);   // 2 workgroups per CU (160 KiB / 2, minus rounding)
   uint32_t stage_bytes = env_u32("SGPU_STAGE_BYTES", 0);
   if (!stage_bytes) {
     stage_bytes = target > o + 8192 ? target - o : 8192;
     stage_bytes = std::min<uint32_t>(stage_bytes, 64 * 1024);
   }
-  stage_bytes = std::max<uint32_t>(stage_bytes, qc * 64 * 8);
+  stage_bytes = std::max<uint32_t>(stage_bytes, qc * 128 * 8);
   const uint32_t uni = up16(std::max(std::max(chunk_bytes, sort_bytes), stage_bytes));
   o += uni;
   L.qc = qc;
@@ -358,6 +428,7 @@ static sgpu_status configure(DeviceIndex* d, const sgpu_batch* b, const sgpu_sea
   a->p.stage_cap = uni / 8;
   a->p.items_max = items_max;
   a->p.items_init = std::min<uint32_t>(items_max, env_u32("SGPU_ITEMS_INIT", 128));
+  a->p.items_min = std::min<uint32_t>(a->p.items_init, env_u32("SGPU_ITEMS_MIN", 64));
   a->p.rblocks_max = env_u32("SGPU_RBLOCKS", 8);
   a->p.target_list = mode == MODE_DOTS ? sp.query_cut : 0;
   a->ix = d->view;
@@ -373,6 +444,8 @@ static sgpu_status configure(DeviceIndex* d, const sgpu_batch* b, const sgpu_sea
   a->qb.out_scores = b->out_scores;
   a->qb.out_ids = b->out_ids;
   a->qb.out_n = b->out_n;
+  a->qb.q_order = d_order;
+  a->qb.out_stats = mode == MODE_SEARCH ? b->out_stats : nullptr;
   int per_cu = 0;
   HIP_TRY(occupancy_search(*a, &per_cu));
   if (per_cu < 1) return fail(SGPU_ELIMIT, "the search kernel does not fit on a CU with %u bytes of LDS", o);
@@ -427,6 +500,7 @@ sgpu_status batch_run(DeviceIndex* d, sgpu_batch* b, const sgpu_search_params& s
     drain_events(d);
   }
   HIP_TRY(hipMemsetAsync(d->queue, 0, 4, d->stream));
+  if (a.qb.out_stats) HIP_TRY(hipMemsetAsync(b->out_stats, 0, (size_t)b->nq * STATS_WORDS * 4, d->stream));
   const int e = d->ev_pending++;
   HIP_TRY(hipEventRecord(d->ev0[e], d->stream));
   HIP_TRY(launch_search(a));
@@ -475,6 +549,15 @@ sgpu_status batch_fetch(DeviceIndex* d, sgpu_batch* b, uint32_t k, float* out_sc
   HIP_TRY(hipMemcpy2D(out_ids, (size_t)k * 8, b->out_ids, (size_t)b->k_max * 8, (size_t)k * 8, b->nq,
                       hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(out_n, b->out_n, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
+  return SGPU_OK;
+}
+
+sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out) {
+  if (!d || !b || !out) return fail(SGPU_EINVAL, "null index/batch/out");
+  std::lock_guard<std::mutex> lock(d->mu);
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  if (b->nq) HIP_TRY(hipMemcpy(out, b->out_stats, (size_t)b->nq * STATS_WORDS * 4, hipMemcpyDeviceToHost));
   return SGPU_OK;
 }
 

@@ -33,9 +33,12 @@ struct BatchView {
   float* out_scores;
   uint64_t* out_ids;
   uint32_t* out_n;
+  const uint32_t* q_order; // optional processing order (queue ticket -> query), longest expected first
+  uint32_t* out_stats;     // optional nq x STATS_WORDS counters (zeroed by the host before a pass)
 };
 
 enum { MODE_SEARCH = 0, MODE_DOTS = 1 };
+enum { STATS_WORDS = 24 };   // per-query stats: 8 work counters + 12 phase clocks (>>4) + slot + pad
 
 struct KParams {
   uint32_t k, query_cut;
@@ -44,7 +47,8 @@ struct KParams {
   uint32_t mode;
   uint32_t stage_cap;    // staging entries (8 B each) available in the union region
   uint32_t items_max;    // speculative documents per round (LDS item table)
-  uint32_t items_init;   // first round's budget; doubles every round
+  uint32_t items_init;   // first round's budget; adapts to the replay's keep ratio
+  uint32_t items_min;    // lower bound of the budget
   uint32_t rblocks_max;  // blocks filtered per thread and round
   uint32_t target_list;  // MODE_DOTS: the posting list whose summary dots are wanted
 };

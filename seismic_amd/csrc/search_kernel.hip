@@ -71,6 +71,17 @@ SGPU_DEV float half_bits_to_float(uint32_t h) {   // exact binary16 -> binary32 
 
 SGPU_DEV uint32_t lane_id() { return __lane_id(); }
 
+// value of `v` in lane `l`, l wave-uniform (v_readlane_b32; no LDS round trip)
+SGPU_DEV uint32_t readlane_u(uint32_t v, uint32_t l) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)l));
+}
+SGPU_DEV float readlane_f(float v, uint32_t l) { return __uint_as_float(readlane_u(__float_as_uint(v), l)); }
+// lane i receives lane i-1's value, lane 0 keeps its own (DPP wave_shr:1)
+SGPU_DEV uint32_t shift_up1_u(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
+SGPU_DEV float shift_up1_f(float v) { return __uint_as_float(shift_up1_u(__float_as_uint(v))); }
+
 // inclusive scan of one u32 per thread over the whole workgroup.
 // `part` points to NT/64 + 1 LDS words. Returns inclusive prefix; *total = sum.
 template <int NT>
@@ -102,8 +113,7 @@ SGPU_DEV uint32_t wg_inclusive_scan(uint32_t v, uint32_t* part, uint32_t* total)
 struct Lds {
   uint32_t* q_comp;
   float* q_val;
-  uint32_t* q_bits;
-  uint16_t* q_rank;
+  uint2* q_word;        // [ceil(dim/32)] {32 vocabulary bits, rank of the word's first query component}
   uint32_t* sel_comp;   // [QC] list (component) ids in traversal order
   uint32_t* sel_nb;     // [QC] blocks in the list
   uint32_t* sel_b0;     // [QC] first global block id
@@ -124,8 +134,7 @@ SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
   Lds l;
   l.q_comp = (uint32_t*)(smem + L.q_comp);
   l.q_val = (float*)(smem + L.q_val);
-  l.q_bits = (uint32_t*)(smem + L.q_bits);
-  l.q_rank = (uint16_t*)(smem + L.q_rank);
+  l.q_word = (uint2*)(smem + L.q_bits);
   l.sel_comp = (uint32_t*)(smem + L.sel);
   l.sel_nb = l.sel_comp + L.qc;
   l.sel_b0 = l.sel_nb + L.qc;
@@ -153,16 +162,16 @@ SGPU_DEV void load_query(const Lds& s, const BatchView& qb, uint32_t q, uint32_t
     const uint32_t c = qb.q_comp[o0 + j];
     s.q_comp[j] = c;
     s.q_val[j] = qb.q_val[o0 + j];
-    atomicOr(&s.q_bits[c >> 5], 1u << (c & 31));
+    atomicOr(&s.q_word[c >> 5].x, 1u << (c & 31));
     // rank of the first query component of each vocabulary word
-    if (j == 0 || (qb.q_comp[o0 + j - 1] >> 5) != (c >> 5)) s.q_rank[c >> 5] = (uint16_t)j;
+    if (j == 0 || (qb.q_comp[o0 + j - 1] >> 5) != (c >> 5)) s.q_word[c >> 5].y = j;
   }
   *nnz_out = nnz;
 }
 
 template <int NT>
 SGPU_DEV void clear_query_bits(const Lds& s, uint32_t nnz) {
-  for (uint32_t j = threadIdx.x; j < nnz; j += NT) s.q_bits[s.q_comp[j] >> 5] = 0;
+  for (uint32_t j = threadIdx.x; j < nnz; j += NT) s.q_word[s.q_comp[j] >> 5].x = 0;
 }
 
 // k_largest_by(query_cut, total_cmp) in descending order; ties: ascending component.
@@ -259,7 +268,9 @@ SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32
   const uint32_t total_blocks = s.sel_doff[nl];
   for (uint32_t i = threadIdx.x; i < total_blocks; i += NT) s.dots[i] = 0.0f;
   uint2* stage = (uint2*)s.uni;
-  const uint32_t cap_l = (stage_cap / nl) & ~63u;   // staging window per list
+  uint32_t cap_shift = 6;                           // staging window per list: a power of two >= 64
+  while ((2u << cap_shift) * nl <= stage_cap) ++cap_shift;
+  const uint32_t cap_l = 1u << cap_shift;
   uint32_t emax = 0;
   for (uint32_t l = 0; l < nl; ++l) {
     const uint32_t e = s.rt_pre[l * (qn + 1) + nnz];
@@ -267,22 +278,47 @@ SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32
   }
   __syncthreads();
   for (uint32_t w0 = 0; w0 < emax; w0 += cap_l) {
-    for (uint32_t t = wave; t < nl * nnz; t += NW) {
-      const uint32_t l = t / nnz, j = t - l * nnz;
-      const uint32_t p0 = s.rt_pre[l * (qn + 1) + j], p1 = s.rt_pre[l * (qn + 1) + j + 1];
-      const uint32_t a = p0 > w0 ? p0 : w0;
-      const uint32_t b = p1 < w0 + cap_l ? p1 : w0 + cap_l;
-      if (a >= b) continue;
-      const uint32_t gstart = s.rt_start[l * qn + j];
-      const float2* mq = ix.blk_mq + s.sel_b0[l];
-      const float qv = s.q_val[j];
-      for (uint32_t f = a + lane; f < b; f += 64) {
-        const uint32_t g = gstart + (f - p0);
-        const uint32_t bid = ix.sum_bid[g];
-        const float code = (float)ix.sum_code[g];
-        const float2 m = mq[bid];   // (min, quant): 8 B per block, L2-resident for the list
-        const float prod = __fmul_rn(__fadd_rn(__fmul_rn(code, m.y), m.x), qv);
-        stage[l * cap_l + (f - w0)] = make_uint2(bid, __float_as_uint(prod));
+    // thread per entry over the flattened (list, position) window, 4 independent entries in
+    // flight per thread: row lookup by binary search in LDS, then HBM loads back to back.
+    const uint32_t span = nl << cap_shift;
+    for (uint32_t base = threadIdx.x; base < span; base += 4 * NT) {
+      uint32_t sidx[4], g[4], lb0[4];
+      float qv[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t idx = base + (uint32_t)u * NT;
+        const uint32_t l = idx >> cap_shift;
+        const uint32_t f = w0 + (idx & (cap_l - 1));
+        ok[u] = idx < span;
+        const uint32_t* pre = s.rt_pre + (ok[u] ? l : 0u) * (qn + 1);
+        ok[u] = ok[u] && f < pre[nnz];
+        uint32_t lo = 0, hi = nnz;   // last row j with pre[j] <= f
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (pre[mid] <= f) lo = mid; else hi = mid;
+        }
+        sidx[u] = idx;
+        g[u] = ok[u] ? s.rt_start[l * qn + lo] + (f - pre[lo]) : 0u;
+        qv[u] = s.q_val[lo];
+        lb0[u] = ok[u] ? s.sel_b0[l] : 0u;
+      }
+      uint32_t bid[4];
+      float code[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bid[u] = ok[u] ? (uint32_t)ix.sum_bid[g[u]] : 0u;
+        code[u] = ok[u] ? (float)ix.sum_code[g[u]] : 0.0f;
+      }
+      float2 m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) m[u] = ok[u] ? ix.blk_mq[lb0[u] + bid[u]] : make_float2(0.f, 0.f);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ok[u]) {
+          const float prod = __fmul_rn(__fadd_rn(__fmul_rn(code[u], m[u].y), m[u].x), qv[u]);
+          stage[sidx[u]] = make_uint2(bid[u], __float_as_uint(prod));
+        }
       }
     }
     __syncthreads();
@@ -349,7 +385,9 @@ struct RegHeap {
   float sc[KR];
   uint32_t doc[KR];
   uint32_t len;   // wave-uniform
+  float thr;      // wave-uniform: score of entry k-1 once len == k
   SGPU_DEV void reset() {
+    thr = 0.0f;
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
       sc[r] = -__builtin_inff();
@@ -368,11 +406,11 @@ struct RegHeap {
     }
 #pragma unroll
     for (int r = KR - 1; r >= 0; --r) {
-      float ps = __shfl_up(sc[r], 1);
-      uint32_t pd = __shfl_up(doc[r], 1);
+      float ps = shift_up1_f(sc[r]);
+      uint32_t pd = shift_up1_u(doc[r]);
       if (r > 0) {
-        const float cs = __shfl(sc[r - 1], 63);
-        const uint32_t cd = __shfl(doc[r - 1], 63);
+        const float cs = readlane_f(sc[r - 1], 63);
+        const uint32_t cd = readlane_u(doc[r - 1], 63);
         if (lane == 0) {
           ps = cs;
           pd = cd;
@@ -392,12 +430,13 @@ struct RegHeap {
       }
     }
     if (len < k) ++len;
+    if (len == k) thr = kth(k);
   }
   SGPU_DEV float kth(uint32_t k) const {   // score of entry k-1 (valid when len == k)
     float v = 0.0f;
 #pragma unroll
     for (int r = 0; r < KR; ++r) {
-      const float x = __shfl(sc[r], (int)((k - 1) & 63));
+      const float x = readlane_f(sc[r], (k - 1) & 63);
       if ((uint32_t)r == ((k - 1) >> 6)) v = x;
     }
     return v;
@@ -412,9 +451,10 @@ struct ChunkBufs {   // carved from the union region
   uint32_t* cb_incl;    // [NT] inclusive item prefix
   uint32_t* cb_p0;      // [NT] first posting of the block
   uint16_t* cb_blk;     // [NT] block id (list-local)
-  uint64_t* it_ref;     // [ITEMS] packed doc record ref; low 32 bits reused for the score
+  uint64_t* it_ref;     // [ITEMS] packed doc record ref; high 32 bits reused for the score
   uint32_t* it_doc;     // [ITEMS] doc id | (already visited) << 31
   uint16_t* it_blk;     // [ITEMS]
+  float* it_dot;        // [ITEMS] summary dot of the item's block
 };
 
 template <int NT>
@@ -423,6 +463,7 @@ SGPU_DEV ChunkBufs carve_chunk(uint8_t* uni, uint32_t items_max) {
   uint8_t* p = uni;
   c.it_ref = (uint64_t*)p;  p += (size_t)items_max * 8;
   c.it_doc = (uint32_t*)p;  p += (size_t)items_max * 4;
+  c.it_dot = (float*)p;     p += (size_t)items_max * 4;
   c.cb_incl = (uint32_t*)p; p += NT * 4;
   c.cb_p0 = (uint32_t*)p;   p += NT * 4;
   c.it_blk = (uint16_t*)p;  p += (size_t)items_max * 2;
@@ -444,65 +485,93 @@ SGPU_DEV void visited_mark(uint32_t* bitmap, uint32_t doc) {
 // QueryEvaluator::compute_distance for one document by one 16-lane group.
 // Canonical order: lane j accumulates elements [128 s + 8 j, +8) in
 // increasing index, then t[j] += t[j ^ d] for d = 8, 4, 2, 1.
+// Non-matching components resolve to the weight 0.0 (slot qn of q_val) and are
+// added as +-0.0, which leaves an accumulator that started at +0.0 bit-identical
+// to skipping them (x + (+-0) == x, and the accumulator can never be -0.0).
 template <typename CT>
-SGPU_DEV float score_document(const Lds& s, const uint8_t* fwd, uint64_t ref, uint32_t sub) {
-  const uint32_t len = (uint32_t)(ref & 0xffffu);
-  const uint32_t npad = (len + 7u) & ~7u;
-  const uint8_t* rec = fwd + (ref >> 16) * 16ull;
-  const uint8_t* vals = rec + (size_t)npad * sizeof(CT);
-  float acc = 0.0f;
-  for (uint32_t e0 = sub * 8u; e0 < len; e0 += 128u) {
-    uint32_t c[8];
-    if (sizeof(CT) == 2) {
-      const uint4 cw = *(const uint4*)(rec + (size_t)e0 * 2);
-      c[0] = cw.x & 0xffffu; c[1] = cw.x >> 16; c[2] = cw.y & 0xffffu; c[3] = cw.y >> 16;
-      c[4] = cw.z & 0xffffu; c[5] = cw.z >> 16; c[6] = cw.w & 0xffffu; c[7] = cw.w >> 16;
-    } else {
-      const uint4 c0 = *(const uint4*)(rec + (size_t)e0 * 4);
-      const uint4 c1 = *(const uint4*)(rec + (size_t)e0 * 4 + 16);
-      c[0] = c0.x; c[1] = c0.y; c[2] = c0.z; c[3] = c0.w;
-      c[4] = c1.x; c[5] = c1.y; c[6] = c1.z; c[7] = c1.w;
-    }
-    const uint4 vw = *(const uint4*)(vals + (size_t)e0 * 2);
-    const uint32_t v[4] = {vw.x, vw.y, vw.z, vw.w};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (e0 + (uint32_t)i < len) {
-        const uint32_t comp = c[i];
-        const uint32_t w = s.q_bits[comp >> 5];
-        const uint32_t bit = comp & 31u;
-        if ((w >> bit) & 1u) {
-          const uint32_t r = (uint32_t)s.q_rank[comp >> 5] + (uint32_t)__popc(w & ((1u << bit) - 1u));
-          const float dv = half_bits_to_float((v[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
-          acc = __fadd_rn(acc, __fmul_rn(s.q_val[r], dv));
-        }
-      }
-    }
+struct DocChunk {   // 8 consecutive elements of one document, as loaded
+  uint4 c0, c1, v;
+};
+
+template <typename CT>
+SGPU_DEV void load_chunk(DocChunk<CT>& d, const uint8_t* rec, const uint8_t* vals, uint32_t e0) {
+  if (sizeof(CT) == 2) {
+    d.c0 = *(const uint4*)(rec + (size_t)e0 * 2);
+  } else {
+    d.c0 = *(const uint4*)(rec + (size_t)e0 * 4);
+    d.c1 = *(const uint4*)(rec + (size_t)e0 * 4 + 16);
   }
+  d.v = *(const uint4*)(vals + (size_t)e0 * 2);
+}
+
+template <typename CT>
+SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0, uint32_t len, uint32_t qn,
+                                float acc) {
+  uint32_t c[8];
+  if (sizeof(CT) == 2) {
+    c[0] = d.c0.x & 0xffffu; c[1] = d.c0.x >> 16; c[2] = d.c0.y & 0xffffu; c[3] = d.c0.y >> 16;
+    c[4] = d.c0.z & 0xffffu; c[5] = d.c0.z >> 16; c[6] = d.c0.w & 0xffffu; c[7] = d.c0.w >> 16;
+  } else {
+    c[0] = d.c0.x; c[1] = d.c0.y; c[2] = d.c0.z; c[3] = d.c0.w;
+    c[4] = d.c1.x; c[5] = d.c1.y; c[6] = d.c1.z; c[7] = d.c1.w;
+  }
+  const uint32_t v[4] = {d.v.x, d.v.y, d.v.z, d.v.w};
+  uint2 w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = s.q_word[c[i] >> 5];
+  uint32_t r[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t bit = c[i] & 31u;
+    const bool hit = ((w[i].x >> bit) & 1u) && (e0 + (uint32_t)i < len);
+    r[i] = hit ? w[i].y + (uint32_t)__popc(w[i].x & ((1u << bit) - 1u)) : qn;
+  }
+  float qv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) qv[i] = s.q_val[r[i]];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float dv = half_bits_to_float((v[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
+    acc = __fadd_rn(acc, __fmul_rn(qv[i], dv));
+  }
+  return acc;
+}
+
+SGPU_DEV float reduce16(float acc) {
 #pragma unroll
   for (int d = 8; d >= 1; d >>= 1) acc = __fadd_rn(acc, __shfl_xor(acc, d, 16));
   return acc;
 }
 
+// Work the reference algorithm performs for this query (lane-local partial counts, wave 0).
+struct WorkCount {
+  uint32_t blocks, posts, docs, len;
+};
+
 // Sequential replay of the reference's decisions over the chunk's items (wavefront 0 only).
 template <int KR>
 SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, const float* dots, uint32_t n_items,
-                           uint32_t k, float heap_factor, uint32_t* bitmap, uint32_t& decided_blk) {
+                           uint32_t k, float heap_factor, uint32_t* bitmap, uint32_t& decided_blk,
+                           bool block_starts_at_0, WorkCount& wc, uint32_t& live_items) {
   const uint32_t lane = lane_id();
-  const float* it_score = (const float*)cb.it_ref;   // low word of each 8-byte slot
+  const uint32_t* it_words = (const uint32_t*)cb.it_ref;   // [2i] = low ref word (len), [2i+1] = score
   uint32_t i = 0;
   while (i < n_items) {
     const uint32_t idx = i + lane;
     const bool valid = idx < n_items;
     float sc = 0.0f;
-    uint32_t doc = 0, blk = 0;
-    bool vis = true;
+    uint32_t doc = 0, blk = 0, len = 0;
+    float bdot = 0.0f;
+    bool vis = true, first = false;
     if (valid) {
-      sc = it_score[2 * idx];
+      bdot = cb.it_dot[idx];
+      sc = __uint_as_float(it_words[2 * idx + 1]);
+      len = it_words[2 * idx] & 0xffffu;
       const uint32_t d = cb.it_doc[idx];
       doc = d & 0x7fffffffu;
       vis = (d >> 31) != 0;
       blk = cb.it_blk[idx];
+      first = idx == 0 ? block_starts_at_0 : (cb.it_blk[idx - 1] != blk);
     }
     if (heap.len < k) {
       // heap not full: every block that starts now is evaluated, every new doc is pushed
@@ -514,33 +583,49 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, const float* 
       uint32_t last;   // window position of the last item consumed in this step
       if ((uint32_t)__popcll(nvm) >= need) last = 63u - (uint32_t)__clzll(tm);
       else last = (n_items - i < 64u ? n_items - i : 64u) - 1u;
-      if (take) visited_mark(bitmap, doc);
-      // push the taken items one by one (k is small while filling)
+      if (take) {
+        visited_mark(bitmap, doc);
+        wc.docs += 1;
+        wc.len += len;
+      }
+      if (valid && lane <= last) {
+        wc.posts += 1;
+        wc.blocks += first;
+      }
+      live_items += last + 1;
       uint64_t m = tm;
       while (m) {
         const int l = __ffsll((long long)m) - 1;
         m &= m - 1;
-        heap.insert(__shfl(sc, l), __shfl(doc, l), k);
+        heap.insert(readlane_f(sc, (uint32_t)l), readlane_u(doc, (uint32_t)l), k);
       }
-      decided_blk = __shfl(blk, (int)last);
+      decided_blk = readlane_u(blk, last);
       i += last + 1;
       continue;
     }
-    const float thr = heap.kth(k);
+    const float thr = heap.thr;
     const float cut = __fmul_rn(heap_factor, thr);
-    const bool live = valid && ((blk == decided_blk) || !(dots[blk] < cut));
+    const bool live = valid && ((blk == decided_blk) || !(bdot < cut));
     const bool changing = live && !vis && (sc > thr);
     const uint64_t cm = __ballot(changing);
+    const uint32_t f = cm ? (uint32_t)(__ffsll((long long)cm) - 1) : 63u;
+    live_items += (uint32_t)__popcll(__ballot(live && lane <= f));
+    if (live && lane <= f) {
+      wc.posts += 1;
+      wc.blocks += first;
+      if (!vis) {
+        visited_mark(bitmap, doc);
+        wc.docs += 1;
+        wc.len += len;
+      }
+    }
     if (cm == 0) {
-      if (live && !vis) visited_mark(bitmap, doc);
       i += 64;
       continue;
     }
-    const int f = __ffsll((long long)cm) - 1;
-    if (live && !vis && lane <= (uint32_t)f) visited_mark(bitmap, doc);
-    heap.insert(__shfl(sc, f), __shfl(doc, f), k);
-    decided_blk = __shfl(blk, f);
-    i += (uint32_t)f + 1;
+    heap.insert(readlane_f(sc, f), readlane_u(doc, f), k);
+    decided_blk = readlane_u(blk, f);
+    i += f + 1;
   }
 }
 
@@ -548,7 +633,7 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, const float* 
 // the kernel
 // ---------------------------------------------------------------------------
 template <typename CT, int NT, int KR>
-__global__ __launch_bounds__(NT) void seismic_search_kernel(DevView ix, BatchView qb, KParams p,
+__global__ __launch_bounds__(NT, 4) void seismic_search_kernel(DevView ix, BatchView qb, KParams p,
                                                            LdsLayout L, uint32_t* queue,
                                                            uint32_t* bitmaps) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -557,21 +642,40 @@ __global__ __launch_bounds__(NT) void seismic_search_kernel(DevView ix, BatchVie
   uint32_t* bitmap = bitmaps + (size_t)blockIdx.x * ix.n_bitmap_words;
   const ChunkBufs cb = carve_chunk<NT>(s.uni, p.items_max);
   RegHeap<KR> heap;   // meaningful in wavefront 0
+  WorkCount wc;       // lane-local partial counts, wavefront 0
 
   // one-time LDS init
-  for (uint32_t i = threadIdx.x; i < (ix.dim + 31) / 32; i += NT) s.q_bits[i] = 0;
+  for (uint32_t i = threadIdx.x; i < (ix.dim + 31) / 32; i += NT) s.q_word[i] = make_uint2(0u, 0u);
+  if (threadIdx.x == 0) s.q_val[L.qn] = 0.0f;   // the weight every non-matching component resolves to
   __syncthreads();
 
   for (;;) {
-    if (threadIdx.x == 0) s.st[ST_Q] = atomicAdd(queue, 1u);
+    if (threadIdx.x == 0) {
+      const uint32_t ticket = atomicAdd(queue, 1u);
+      // longest-expected-first order prepared by the host (tail balance); identity if absent
+      s.st[ST_Q] = ticket < qb.nq ? (qb.q_order ? qb.q_order[ticket] : ticket) : 0xffffffffu;
+    }
     __syncthreads();
     const uint32_t q = s.st[ST_Q];
-    if (q >= qb.nq) break;
+    if (q == 0xffffffffu) break;
 
+    // phase clocks (s_memtime): time since the previous TICK goes to bucket i
+    uint32_t prof[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) prof[i] = 0;
+    uint64_t tprev = clock64();
+#define TICK(i)                                   \
+  {                                               \
+    const uint64_t t_ = clock64();                \
+    prof[i] += (uint32_t)((t_ - tprev) >> 4);     \
+    tprev = t_;                                   \
+  }
     // ---- stage 0 ----
     uint32_t nnz;
     load_query<NT>(s, qb, q, &nnz);
     heap.reset();
+    wc = WorkCount{0, 0, 0, 0};
+    uint32_t spec_docs = 0, st_entries = 0, st_rows = 0;
     if (threadIdx.x == 0) {
       s.st[ST_HLEN] = 0;
       s.st[ST_THR] = 0;
@@ -592,11 +696,21 @@ __global__ __launch_bounds__(NT) void seismic_search_kernel(DevView ix, BatchVie
     }
     __syncthreads();
     const uint32_t nl = s.st[ST_NLISTS];
+    TICK(0);
 
     if (nl > 0) {
       // ---- stage 1 ----
       build_row_table<CT, NT>(s, ix, nnz, nl, L.qn);
+      TICK(1);
+      if (qb.out_stats && threadIdx.x == 0) {
+        for (uint32_t l = 0; l < nl; ++l) {
+          const uint32_t* pre = s.rt_pre + l * (L.qn + 1);
+          st_entries += pre[nnz];
+          for (uint32_t j = 0; j < nnz; ++j) st_rows += pre[j + 1] != pre[j];
+        }
+      }
       summary_dots<NT>(s, ix, nnz, nl, L.qn, p.stage_cap);
+      TICK(2);
 
       if (p.mode == MODE_DOTS) {   // sgpu_summary_distances: dump the dots of list 0
         for (uint32_t i = threadIdx.x; i < s.sel_nb[0]; i += NT) qb.out_scores[i] = s.dots[i];
@@ -615,6 +729,7 @@ __global__ __launch_bounds__(NT) void seismic_search_kernel(DevView ix, BatchVie
         const float* dots = s.dots + s.sel_doff[l];
         const bool sorted = (l == 0) && p.first_sorted && nb > 1;
         if (sorted) sort_first_list<NT>(s, nb);
+        TICK(3);
         uint32_t decided_blk = 0xffffffffu;   // wavefront 0 state
         uint32_t pos = 0;
         while (pos < nb) {
@@ -639,6 +754,7 @@ __global__ __launch_bounds__(NT) void seismic_search_kernel(DevView ix, BatchVie
           const uint32_t live_incl = wg_inclusive_scan<NT>(my_live, s.part, &n_live_total);
           if (n_live_total == 0) {
             pos = scan_end;
+            TICK(4);
             continue;
           }
           {
@@ -653,6 +769,7 @@ __global__ __launch_bounds__(NT) void seismic_search_kernel(DevView ix, BatchVie
           }
           const uint32_t n_live = n_live_total < NT ? n_live_total : NT;
           __syncthreads();
+          TICK(4);
           // (b) postings of the live blocks, budget cut
           uint32_t cnt = 0, p0 = 0, myb = 0;
           if (threadIdx.x < n_live) {
@@ -687,6 +804,8 @@ __global__ __launch_bounds__(NT) void seismic_search_kernel(DevView ix, BatchVie
           }
           if (nblk == n_live && n_live == n_live_total) next_pos = scan_end;
           else next_pos = (uint32_t)cb.live_pos[nblk - 1] + 1;
+          TICK(5);
+          prof[10] += 1;
 
           for (uint32_t piece = 0; piece < n_pieces; ++piece) {
             uint32_t n_items, item0 = 0;
@@ -712,34 +831,79 @@ __global__ __launch_bounds__(NT) void seismic_search_kernel(DevView ix, BatchVie
               const uint32_t vis = visited_test(bitmap, doc) ? 0x80000000u : 0u;
               cb.it_ref[i] = ref;
               cb.it_doc[i] = doc | vis;
-              cb.it_blk[i] = cb.cb_blk[lo];
+              const uint32_t blk = cb.cb_blk[lo];
+              cb.it_blk[i] = (uint16_t)blk;
+              cb.it_dot[i] = dots[blk];
             }
             __syncthreads();
-            // (d) phase B: speculative scoring, 16 lanes per document
+            TICK(6);
+            // (d) phase B: speculative scoring, 16 lanes per document, two documents in flight
             {
               const uint32_t grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
-              for (uint32_t i = grp; i < n_items; i += NT / 16) {
-                const uint64_t ref = cb.it_ref[i];
-                const bool vis = (cb.it_doc[i] >> 31) != 0;
-                float sc = 0.0f;
-                if (!vis) sc = score_document<CT>(s, ix.fwd, ref, sub);
-                if (sub == 0) ((float*)cb.it_ref)[2 * i] = sc;
+              constexpr uint32_t G = NT / 16;
+              float* it_score = (float*)cb.it_ref;
+              for (uint32_t i = grp; i < n_items; i += 2 * G) {
+                const uint32_t i1 = i + G;
+                const bool has1 = i1 < n_items;
+                const uint64_t ref0 = cb.it_ref[i];
+                const uint64_t ref1 = has1 ? cb.it_ref[i1] : 0ull;
+                const bool do0 = (cb.it_doc[i] >> 31) == 0;
+                const bool do1 = has1 && (cb.it_doc[i1] >> 31) == 0;
+                const uint32_t len0 = do0 ? (uint32_t)(ref0 & 0xffffu) : 0u;
+                const uint32_t len1 = do1 ? (uint32_t)(ref1 & 0xffffu) : 0u;
+                const uint8_t* rec0 = ix.fwd + (ref0 >> 16) * 16ull;
+                const uint8_t* rec1 = ix.fwd + (ref1 >> 16) * 16ull;
+                const uint8_t* val0 = rec0 + (size_t)((len0 + 7u) & ~7u) * sizeof(CT);
+                const uint8_t* val1 = rec1 + (size_t)((len1 + 7u) & ~7u) * sizeof(CT);
+                const uint32_t e0 = sub * 8u;
+                DocChunk<CT> d0, d1;
+                d0.c0 = d0.c1 = d0.v = make_uint4(0, 0, 0, 0);
+                d1 = d0;
+                if (e0 < len0) load_chunk<CT>(d0, rec0, val0, e0);
+                if (e0 < len1) load_chunk<CT>(d1, rec1, val1, e0);
+                float a0 = 0.0f, a1 = 0.0f;
+                if (e0 < len0) a0 = accumulate_chunk<CT>(s, d0, e0, len0, L.qn, a0);
+                if (e0 < len1) a1 = accumulate_chunk<CT>(s, d1, e0, len1, L.qn, a1);
+                for (uint32_t e = e0 + 128u; e < len0; e += 128u) {   // documents longer than 128
+                  load_chunk<CT>(d0, rec0, val0, e);
+                  a0 = accumulate_chunk<CT>(s, d0, e, len0, L.qn, a0);
+                }
+                for (uint32_t e = e0 + 128u; e < len1; e += 128u) {
+                  load_chunk<CT>(d1, rec1, val1, e);
+                  a1 = accumulate_chunk<CT>(s, d1, e, len1, L.qn, a1);
+                }
+                a0 = reduce16(a0);
+                a1 = reduce16(a1);
+                spec_docs += (sub == 0 && do0) + (sub == 0 && do1);
+                if (sub == 0) {
+                  it_score[2 * i + 1] = a0;
+                  if (has1) it_score[2 * i1 + 1] = a1;
+                }
               }
             }
             __syncthreads();
+            TICK(7);
             // (e) exact replay on wavefront 0
             if (wave == 0) {
-              replay_chunk<KR>(heap, cb, dots, n_items, p.k, p.heap_factor, bitmap, decided_blk);
+              uint32_t live_items = 0;
+              replay_chunk<KR>(heap, cb, dots, n_items, p.k, p.heap_factor, bitmap, decided_blk, piece == 0, wc,
+                               live_items);
               if (lane == 0) {
                 s.st[ST_HLEN] = heap.len;
-                s.st[ST_THR] = __float_as_uint(heap.len == p.k ? heap.kth(p.k) : 0.0f);
+                s.st[ST_THR] = __float_as_uint(heap.len == p.k ? heap.thr : 0.0f);
+                s.st[ST_TMP1] = live_items;
               }
             }
             __syncthreads();
+            TICK(8);
           }
-          (void)piece_items;
           pos = next_pos;
-          budget = budget * 2 < p.items_max ? budget * 2 : p.items_max;
+          // adapt the speculation budget to how much of the last round the replay kept
+          {
+            const uint32_t kept = s.st[ST_TMP1];
+            if (kept * 4 >= piece_items * 3) budget = budget * 2 < p.items_max ? budget * 2 : p.items_max;
+            else if (kept * 2 < piece_items) budget = budget / 2 > p.items_min ? budget / 2 : p.items_min;
+          }
         }
       }
     }
@@ -758,11 +922,44 @@ __global__ __launch_bounds__(NT) void seismic_search_kernel(DevView ix, BatchVie
       }
       if (lane == 0) qb.out_n[q] = heap.len;
     }
+    if (qb.out_stats) {   // work counters (see DESIGN.md "Algorithmic bytes")
+      uint32_t sd = spec_docs;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        sd += __shfl_xor(sd, d);
+        wc.blocks += __shfl_xor(wc.blocks, d);
+        wc.posts += __shfl_xor(wc.posts, d);
+        wc.docs += __shfl_xor(wc.docs, d);
+        wc.len += __shfl_xor(wc.len, d);
+      }
+      uint32_t* os = qb.out_stats + (size_t)q * STATS_WORDS;
+      if (lane == 0) atomicAdd(&os[7], sd);
+      if (threadIdx.x == 0) {
+        uint32_t nbt = 0;
+        for (uint32_t l = 0; l < nl; ++l) nbt += s.sel_nb[l];
+        os[0] = nbt;
+        os[1] = st_rows;
+        os[2] = st_entries;
+        os[3] = wc.blocks;
+        os[4] = wc.posts;
+        os[5] = wc.docs;
+        os[6] = wc.len;
+      }
+    }
+    TICK(9);
     // ---- per-query cleanup: visited bitmap, query bits ----
     for (uint32_t i = threadIdx.x; i < ix.n_bitmap_words; i += NT) bitmap[i] = 0;
     clear_query_bits<NT>(s, nnz);
     __threadfence_block();
     __syncthreads();
+    TICK(11);
+    if (qb.out_stats && threadIdx.x == 0) {
+      uint32_t* os = qb.out_stats + (size_t)q * STATS_WORDS + 8;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) os[i] = prof[i];
+      os[12] = blockIdx.x;
+    }
+#undef TICK
   }
 }
 

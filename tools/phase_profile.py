@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Per-phase clock breakdown of the search kernel (counters [8..19] of sgpu_batch_fetch_stats)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from seismic_amd import _native  # noqa: E402
+from seismic_amd._abi import BuildConfig  # noqa: E402
+
+NAMES = ["load+select", "row_table", "summary_dots", "sort", "filter+scan", "postings+cut", "phaseA refs/visited",
+         "phaseB score", "replay", "output", "(n_chunks)", "cleanup"]
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--docs", type=int, default=200000)
+ap.add_argument("--dim", type=int, default=30000)
+ap.add_argument("--queries", type=int, default=1000)
+ap.add_argument("--n-postings", type=int, default=0)
+ap.add_argument("--k", type=int, default=10)
+ap.add_argument("--query-cut", type=int, default=4)
+ap.add_argument("--heap-factor", type=float, default=1.0)
+ap.add_argument("--first-sorted", type=int, default=0)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+npost = a.n_postings or max(1, 2000 * a.docs // 1000000)
+docs = _native.synth(a.docs, a.dim, 42, 0)
+path = "/tmp/prof_%d_%d_%d.idx" % (a.docs, a.dim, npost)
+if os.path.exists(path):
+    ix = _native.NativeIndex.load(path)
+else:
+    t = time.time()
+    ix = _native.NativeIndex.build(2, a.dim, *docs, BuildConfig.defaults(
+        n_postings=npost, centroid_fraction=0.2, summary_energy=0.5, max_fraction=6.0))
+    print("build %.1fs" % (time.time() - t))
+    ix.save(path)
+ix.upload(0)
+q = _native.synth(a.queries, a.dim, 43, 1, docs)
+b = _native.DeviceBatch(ix, *q, a.k)
+for _ in range(2):
+    b.run(a.k, a.query_cut, a.heap_factor, bool(a.first_sorted))
+ms = []
+for _ in range(a.reps):
+    ms.append(b.run(a.k, a.query_cut, a.heap_factor, bool(a.first_sorted)).kernel_ms)
+st = b.fetch_stats().astype(np.float64)
+print("kernel ms: min %.3f med %.3f  | grid %d  env: %s" % (
+    min(ms), sorted(ms)[len(ms) // 2], len(set(st[:, 20].astype(int))),
+    {k: v for k, v in os.environ.items() if k.startswith("SGPU_")}))
+cyc = st[:, 8:20] * 16
+tot = cyc[:, [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 11]].sum(1)
+print("per query: mean total %.0f cycles (%.1f us @2.1GHz), max %.0f; chunks/query %.1f" % (
+    tot.mean(), tot.mean() / 2100, tot.max(), st[:, 18].mean()))
+for i, n in enumerate(NAMES):
+    if i == 10:
+        continue
+    print("  %-22s %9.0f cyc  %5.1f%%" % (n, cyc[:, i].mean(), 100 * cyc[:, i].sum() / tot.sum()))
+print("work/query: blocks %.0f rows %.0f entries %.0f | scored blocks %.0f postings %.0f docs %.0f (spec %.0f)" % tuple(
+    st[:, i].mean() for i in (0, 1, 2, 3, 4, 5, 7)))
+# per-slot busy time: queries per slot and sum
+slots = st[:, 20].astype(int)
+per_slot = np.bincount(slots, weights=tot)
+print("slots used %d, busiest slot %.1f us, mean %.1f us" % ((per_slot > 0).sum(), per_slot.max() / 2100, per_slot[per_slot > 0].mean() / 2100))
