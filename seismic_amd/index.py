@@ -1,0 +1,451 @@
+"""Host-side mirror of the reference's Python API for the search path.
+
+Same class names, argument names, defaults and result shapes as the PyO3 module
+`seismic` (reference src/pylib/mod.rs), so code written against the reference
+switches by changing the import:
+
+    from seismic_amd import SeismicIndex, SeismicDataset, get_seismic_string
+
+  SeismicIndex / SeismicIndexLV        string-keyed (u16 / u32 components)
+      reference: src/pylib/mod.rs:46-661 (search 504-533, batch_search 587-655)
+      wrapper semantics: src/inverted_index_wrapper.rs:58-91, 194-284
+  SeismicIndexRaw / SeismicIndexRawLV  integer-keyed
+      reference: src/pylib/mod.rs:663-1151 (search 1046-1076, batch_search 1111-1146)
+  SeismicDataset / SeismicDatasetLV    in-memory dataset with exact search
+      reference: src/pylib/dataset.rs, src/inverted_index_wrapper.rs:599-758
+
+Search runs on the GPU through the C ABI (include/seismic_hip.h); everything
+here is marshalling: token -> component id (unknown tokens dropped, sorted by
+id), internal id -> document id string. There is no CPU search fallback.
+
+Documented deviations (DESIGN.md "Boundary"):
+  * token ids: tokens are numbered in SORTED order (the reference numbers them
+    in HashMap iteration order, which changes from run to run;
+    scripts/convert_json_to_inner_format.py:188-190 sorts too);
+  * batch_search returns results in INPUT order (the reference's par_bridge
+    does not guarantee any order, src/pylib/mod.rs:629-652);
+  * num_threads is accepted and ignored on the GPU path (it is ineffective in
+    the reference as well: the pool it builds is dropped, src/pylib/mod.rs:599-602);
+  * n_knn / nknn must be 0: the kNN graph is outside this path.
+"""
+import gzip
+import io
+import json
+import os
+import struct
+import tarfile
+
+import numpy as np
+
+from . import _native
+from ._abi import BuildConfig
+
+MAX_TOKEN_LEN = 30
+
+
+def get_seismic_string():
+    """numpy dtype string of token arrays (reference src/pylib/mod.rs:24-25, 41-44)."""
+    return "U%d" % MAX_TOKEN_LEN
+
+
+# ---------------------------------------------------------------------------
+# ingestion (host side; reference src/json_utils.rs:10-78, wrapper 398-552)
+# ---------------------------------------------------------------------------
+def _iter_jsonl(path):
+    if path.endswith(".tar.gz") or path.endswith(".tgz"):
+        with tarfile.open(path, "r:gz") as tar:
+            for member in tar:
+                if not member.isfile():
+                    continue
+                f = tar.extractfile(member)
+                for line in io.TextIOWrapper(f, encoding="utf-8"):
+                    line = line.strip()
+                    if line:
+                        yield json.loads(line)
+        return
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rt", encoding="utf-8") as f:
+        for line in f:
+            line = line.strip()
+            if line:
+                yield json.loads(line)
+
+
+def read_jsonl(path):
+    """rows {id: str|int, vector: {token: weight}, content?: str} -> (ids, [dict], [content])"""
+    ids, vecs, contents = [], [], []
+    try:
+        for row in _iter_jsonl(path):
+            ids.append(str(row["id"]))
+            vecs.append(row["vector"])
+            contents.append(row.get("content"))
+    except (OSError, KeyError, ValueError, tarfile.TarError) as e:
+        raise IOError("Failed to read %s: %s" % (path, e))
+    return ids, vecs, contents
+
+
+def read_inner_format(path, comp_dtype=np.uint32):
+    """Seismic's inner binary format (scripts/convert_json_to_inner_format.py:10-27):
+    u32 n_vecs; per vector: u32 n, n x u32 components (sorted), n x f32 values; little endian."""
+    try:
+        raw = np.fromfile(path, dtype=np.uint8)
+    except OSError as e:
+        raise IOError(str(e))
+    n_vecs = struct.unpack_from("<I", raw, 0)[0]
+    off = np.zeros(n_vecs + 1, np.uint64)
+    comps, vals = [], []
+    p = 4
+    for i in range(n_vecs):
+        n = struct.unpack_from("<I", raw, p)[0]
+        p += 4
+        comps.append(raw[p:p + 4 * n].view("<u4"))
+        p += 4 * n
+        vals.append(raw[p:p + 4 * n].view("<f4"))
+        p += 4 * n
+        off[i + 1] = off[i] + n
+    c = np.concatenate(comps).astype(np.uint32) if comps else np.zeros(0, np.uint32)
+    v = np.concatenate(vals).astype(np.float32) if vals else np.zeros(0, np.float32)
+    return off, c, v
+
+
+def write_inner_format(path, off, comps, vals):
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(off) - 1))
+        for i in range(len(off) - 1):
+            s, e = int(off[i]), int(off[i + 1])
+            f.write(struct.pack("<I", e - s))
+            f.write(np.asarray(comps[s:e], "<u4").tobytes())
+            f.write(np.asarray(vals[s:e], "<f4").tobytes())
+
+
+def _token_map(vecs, given=None):
+    if given is not None:
+        return dict(given)
+    toks = set()
+    for v in vecs:
+        toks.update(v.keys())
+    return {t: i for i, t in enumerate(sorted(toks))}
+
+
+def _to_csr(vecs, token_map):
+    off = np.zeros(len(vecs) + 1, np.uint64)
+    cs, vs = [], []
+    for i, v in enumerate(vecs):
+        items = sorted((token_map[t], w) for t, w in v.items() if t in token_map)
+        off[i + 1] = off[i] + len(items)
+        cs.extend(c for c, _ in items)
+        vs.extend(w for _, w in items)
+    return off, np.asarray(cs, np.uint32), np.asarray(vs, np.float32)
+
+
+def _resolve(tokens, values, token_map):
+    """resolve_query_tokens (reference src/inverted_index_wrapper.rs:75-91): unknown tokens are
+    dropped silently, the rest is sorted by component id."""
+    pairs = sorted((token_map[t], float(v)) for t, v in zip(tokens, values) if t in token_map)
+    # a token repeated in the query would give a duplicate component; keep the first, as a
+    # dict-built query (the documented way to make one) cannot contain duplicates
+    comps, vals, last = [], [], None
+    for c, v in pairs:
+        if c != last:
+            comps.append(c)
+            vals.append(v)
+            last = c
+    return np.asarray(comps, np.uint32), np.asarray(vals, np.float32)
+
+
+def _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy, max_fraction, doc_cut, num_threads):
+    return BuildConfig.defaults(n_postings=int(n_postings), centroid_fraction=float(centroid_fraction),
+                                min_cluster_size=int(min_cluster_size), summary_energy=float(summary_energy),
+                                max_fraction=float(max_fraction), doc_cut=int(doc_cut),
+                                num_threads=int(num_threads))
+
+
+def _no_knn(n):
+    if n:
+        raise ValueError("the kNN graph (nknn / n_knn > 0) is outside the GPU search path of this build")
+
+
+# ---------------------------------------------------------------------------
+class _DatasetBase:
+    """SeismicDataset (reference src/pylib/dataset.rs): add_document + exact search."""
+    _CW = 2
+
+    def __init__(self):
+        self._ids, self._vecs, self._contents = [], [], []
+        self._native = None
+        self._tm = None
+
+    def add_document(self, doc_id, tokens, values, content=None):
+        self._ids.append(str(doc_id))
+        self._vecs.append({str(t): float(v) for t, v in zip(tokens, values)})
+        self._contents.append(content)
+        self._native = None
+
+    @property
+    def len(self):
+        return len(self._ids)
+
+    def _freeze(self):
+        if self._native is None:
+            self._tm = _token_map(self._vecs)
+            off, c, v = _to_csr(self._vecs, self._tm)
+            # exact search only needs the forward index: build with the cheapest valid config
+            self._native = _native.NativeIndex.build(self._CW, max(len(self._tm), 1), off, c, v,
+                                                     _cfg(1, 1.0, 0, 1.0, 1.0, 1, 0))
+        return self._native
+
+    def search(self, query_id, query_components, query_values, k):
+        """Exact top-k (brute force, host cores) -> [(query_id, score, doc_id)]."""
+        ix = self._freeze()
+        c, v = _resolve([str(t) for t in np.asarray(query_components).ravel()],
+                        np.asarray(query_values, np.float32).ravel(), self._tm)
+        sc, ids, n = ix.exact_search(np.array([0, len(c)], np.uint64), c, v, k)
+        return [(str(query_id), float(sc[0, i]), self._ids[int(ids[0, i])]) for i in range(int(n[0]))]
+
+    def batch_search(self, queries_ids, query_components, query_values, k, num_threads=0):
+        return [self.search(q, c, v, k) for q, c, v in zip(np.asarray(queries_ids).ravel(), query_components,
+                                                           query_values)]
+
+
+class SeismicDataset(_DatasetBase):
+    _CW = 2
+
+
+class SeismicDatasetLV(_DatasetBase):
+    _CW = 4
+
+
+# ---------------------------------------------------------------------------
+class _IndexBase:
+    _CW = 2
+
+    def __init__(self, native, token_map, doc_ids, contents=None, device=0, upload=True):
+        self._ix = native
+        self._tm = token_map
+        self._doc_ids = doc_ids
+        self._contents = contents
+        self._device = device
+        self._uploaded = False
+        if upload:
+            self._ensure_device()
+
+    def _ensure_device(self):
+        if not self._uploaded:
+            self._ix.upload(self._device)   # raises if no HIP device: no CPU fallback
+            self._uploaded = True
+
+    # ---- construction -------------------------------------------------
+    @classmethod
+    def build(cls, input_path, n_postings=3500, centroid_fraction=0.1, min_cluster_size=2, summary_energy=0.4,
+              max_fraction=1.5, doc_cut=15, nknn=0, knn_path=None, batched_indexing=None,
+              input_token_to_id_map=None, load_content=True, num_threads=0, device=0, upload=True):
+        """Build from a .jsonl / .jsonl.gz / .tar.gz file (reference src/pylib/mod.rs:329-384)."""
+        _no_knn(nknn or knn_path)
+        ids, vecs, contents = read_jsonl(input_path)
+        tm = _token_map(vecs, input_token_to_id_map)
+        if cls._CW == 2 and len(tm) >= 2 ** 16:
+            raise ValueError("The number of different tokens exceeds 2^16; use SeismicIndexLV")
+        off, c, v = _to_csr(vecs, tm)
+        ix = _native.NativeIndex.build(cls._CW, max(len(tm), 1), off, c, v,
+                                       _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy,
+                                            max_fraction, doc_cut, num_threads))
+        return cls(ix, tm, ids, contents if load_content else None, device, upload)
+
+    @classmethod
+    def build_from_dataset(cls, dataset, n_postings=3500, centroid_fraction=0.1, min_cluster_size=2,
+                           summary_energy=0.4, max_fraction=1.5, doc_cut=15, nknn=0, knn_path=None,
+                           batched_indexing=None, num_threads=0, device=0, upload=True):
+        _no_knn(nknn or knn_path)
+        tm = _token_map(dataset._vecs)
+        off, c, v = _to_csr(dataset._vecs, tm)
+        ix = _native.NativeIndex.build(cls._CW, max(len(tm), 1), off, c, v,
+                                       _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy,
+                                            max_fraction, doc_cut, num_threads))
+        return cls(ix, tm, list(dataset._ids), list(dataset._contents), device, upload)
+
+    @classmethod
+    def load(cls, index_path, device=0, upload=True):
+        """Load `<index_path>.index.sgpu` + `.meta.json` (own format; reference files
+        *.index.seismic use vectorium's serializer, which is not in the reference tree)."""
+        base = index_path[:-len(".index.sgpu")] if index_path.endswith(".index.sgpu") else index_path
+        try:
+            ix = _native.NativeIndex.load(base + ".index.sgpu")
+            with open(base + ".meta.json", "r", encoding="utf-8") as f:
+                meta = json.load(f)
+        except (_native.SeismicHipError, OSError, ValueError) as e:
+            raise IOError("Failed to load index %s: %s" % (index_path, e))
+        return cls(ix, meta["token_to_id_map"], meta["document_mapping"], meta.get("document_content"),
+                   device, upload)
+
+    def save(self, path):
+        try:
+            self._ix.save(path + ".index.sgpu")
+            with open(path + ".meta.json", "w", encoding="utf-8") as f:
+                json.dump({"token_to_id_map": self._tm, "document_mapping": self._doc_ids,
+                           "document_content": self._contents}, f)
+        except (_native.SeismicHipError, OSError) as e:
+            raise IOError("Failed to save index %s: %s" % (path, e))
+
+    # ---- accessors ----------------------------------------------------
+    @property
+    def dim(self):
+        return int(self._ix.desc.dim)
+
+    @property
+    def len(self):
+        return int(self._ix.desc.n_docs)
+
+    @property
+    def nnz(self):
+        return int(self._ix.desc.nnz)
+
+    @property
+    def knn_len(self):
+        return 0
+
+    def get_doc_ids_in_postings(self, list_id):
+        d = self._ix.desc
+        if not 0 <= list_id < d.dim:
+            raise ValueError("Invalid list_id: %d" % list_id)
+        b0, b1 = d.list_block_start[list_id], d.list_block_start[list_id + 1]
+        p0, p1 = d.block_post_start[b0], d.block_post_start[b1]
+        return [int(d.post_doc[p]) for p in range(p0, p1)]
+
+    def print_space_usage_byte(self):
+        d = self._ix.desc
+        cw = d.comp_width
+        fwd = d.nnz * (cw + 2) + (d.n_docs + 1) * 8
+        packed = d.n_postings * 8
+        boffs = (d.n_blocks + d.dim) * 8
+        summ = d.n_entries * 3 + d.n_rows * (cw + 8) + d.n_blocks * 8
+        print("Space Usage:")
+        print("\tForward Index: %d Bytes" % fwd)
+        print("\tPosting Lists: %d Bytes" % (packed + boffs + summ))
+        print("\t  packed_postings: %d Bytes\n\t  block_offsets: %d Bytes\n\t  summaries: %d Bytes"
+              % (packed, boffs, summ))
+        print("\tKnn: 0 Bytes")
+        print("\tTotal: %d Bytes" % (fwd + packed + boffs + summ))
+        print("\tHBM resident: %d Bytes" % self._ix.device_bytes())
+
+    def get_doc_text(self, doc_id):
+        if self._contents is None:
+            return None
+        try:
+            return self._contents[self._doc_ids.index(doc_id)]
+        except ValueError:
+            return None
+
+    # ---- search -------------------------------------------------------
+    def _remap(self, query_id, sc, ids, n):
+        return [(str(query_id), float(sc[i]), self._doc_ids[int(ids[i])]) for i in range(int(n))]
+
+    def search(self, query_id, query_components, query_values, k, query_cut, heap_factor, n_knn=0, sorted=True):
+        """-> [(query_id, score, doc_id)], best first (reference src/pylib/mod.rs:490-533)."""
+        _no_knn(n_knn)
+        self._ensure_device()
+        c, v = _resolve([str(t) for t in np.asarray(query_components).ravel()],
+                        np.asarray(query_values, np.float32).ravel(), self._tm)
+        sc, ids = self._ix.search(c, v, k, query_cut, heap_factor, first_sorted=bool(sorted))
+        return self._remap(query_id, sc, ids, len(ids))
+
+    def batch_search(self, queries_ids, query_components, query_values, k, query_cut, heap_factor, n_knn=0,
+                     sorted=True, num_threads=0):
+        """-> [[(query_id, score, doc_id)]] in input order (reference src/pylib/mod.rs:572-655).
+        One GPU pass over the whole batch."""
+        _no_knn(n_knn)
+        self._ensure_device()
+        qids = [str(x) for x in np.asarray(queries_ids).ravel()]
+        off = np.zeros(len(qids) + 1, np.uint64)
+        cs, vs = [], []
+        for i, (qc, qv) in enumerate(zip(query_components, query_values)):
+            c, v = _resolve([str(t) for t in np.asarray(qc).ravel()], np.asarray(qv, np.float32).ravel(), self._tm)
+            cs.append(c)
+            vs.append(v)
+            off[i + 1] = off[i] + len(c)
+        comps = np.concatenate(cs) if cs else np.zeros(0, np.uint32)
+        vals = np.concatenate(vs) if vs else np.zeros(0, np.float32)
+        sc, ids, n = self._ix.batch_search(off, comps, vals, k, query_cut, heap_factor, first_sorted=bool(sorted))
+        return [self._remap(qids[i], sc[i], ids[i], n[i]) for i in range(len(qids))]
+
+
+class SeismicIndex(_IndexBase):
+    """u16 components (vocabulary < 65536)."""
+    _CW = 2
+
+
+class SeismicIndexLV(_IndexBase):
+    """u32 components: large vocabularies."""
+    _CW = 4
+
+
+# ---------------------------------------------------------------------------
+class _RawBase:
+    """Integer-keyed index over the inner binary format (reference src/pylib/mod.rs:663-1151)."""
+    _CW = 2
+
+    def __init__(self, native, device=0, upload=True):
+        self._ix = native
+        self._device = device
+        self._uploaded = False
+        if upload:
+            self._ensure_device()
+
+    _ensure_device = _IndexBase._ensure_device
+    dim = _IndexBase.dim
+    len = _IndexBase.len
+    nnz = _IndexBase.nnz
+    knn_len = _IndexBase.knn_len
+    get_doc_ids_in_postings = _IndexBase.get_doc_ids_in_postings
+    print_space_usage_byte = _IndexBase.print_space_usage_byte
+
+    @classmethod
+    def build(cls, input_file, n_postings=3500, centroid_fraction=0.1, min_cluster_size=2, summary_energy=0.4,
+              max_fraction=1.5, doc_cut=15, nknn=0, knn_path=None, batched_indexing=None, num_threads=0,
+              device=0, upload=True):
+        _no_knn(nknn or knn_path)
+        off, c, v = read_inner_format(input_file)
+        dim = int(c.max()) + 1 if len(c) else 1
+        if cls._CW == 2 and dim > 65536:
+            raise ValueError("component ids do not fit u16; use SeismicIndexRawLV")
+        ix = _native.NativeIndex.build(cls._CW, dim, off, c, v,
+                                       _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy,
+                                            max_fraction, doc_cut, num_threads))
+        return cls(ix, device, upload)
+
+    @classmethod
+    def load(cls, index_path, device=0, upload=True):
+        try:
+            return cls(_native.NativeIndex.load(index_path), device, upload)
+        except _native.SeismicHipError as e:
+            raise IOError("Failed to load index %s: %s" % (index_path, e))
+
+    def save(self, path):
+        try:
+            self._ix.save(path)
+        except _native.SeismicHipError as e:
+            raise IOError(str(e))
+
+    def search(self, query_components, query_values, k, query_cut, heap_factor, n_knn, sorted):
+        """-> [(score, doc_id)] (reference src/pylib/mod.rs:1033-1076)."""
+        _no_knn(n_knn)
+        self._ensure_device()
+        sc, ids = self._ix.search(np.asarray(query_components).astype(np.uint32),
+                                  np.asarray(query_values, np.float32), k, query_cut, heap_factor,
+                                  first_sorted=bool(sorted))
+        return [(float(s), int(i)) for s, i in zip(sc, ids)]
+
+    def batch_search(self, query_path, k, query_cut, heap_factor, n_knn, sorted, num_threads=0):
+        """queries.bin in the inner format -> [[(score, doc_id)]] in file order (src/pylib/mod.rs:1098-1146)."""
+        _no_knn(n_knn)
+        self._ensure_device()
+        off, c, v = read_inner_format(query_path)
+        sc, ids, n = self._ix.batch_search(off, c, v, k, query_cut, heap_factor, first_sorted=bool(sorted))
+        return [[(float(sc[q, i]), int(ids[q, i])) for i in range(int(n[q]))] for q in range(len(off) - 1)]
+
+
+class SeismicIndexRaw(_RawBase):
+    _CW = 2
+
+
+class SeismicIndexRawLV(_RawBase):
+    _CW = 4

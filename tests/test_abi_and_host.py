@@ -1,0 +1,163 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol the header
+declares; host logic (marshalling, file formats, validation, exact search); loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+import seismic_amd
+from seismic_amd import _native
+from seismic_amd._abi import BuildConfig, IndexDesc
+from seismic_amd.index import _resolve
+from util import random_dataset, random_queries
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_every_declared_symbol_is_exported():
+    hdr = open(os.path.join(ROOT, "include", "seismic_hip.h")).read()
+    names = set(re.findall(r"\b(sgpu_[a-z_0-9]+)\s*\(", hdr))
+    assert len(names) >= 20
+    L = ctypes.CDLL(_native.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.sgpu_abi_version() == 1
+
+
+def test_struct_layouts_match_header_sizes():
+    # sizes implied by the header's field lists (natural alignment)
+    assert ctypes.sizeof(IndexDesc) == 8 + 7 * 8 + 13 * 8
+    assert ctypes.sizeof(BuildConfig) == 32
+    assert ctypes.sizeof(_native.SearchParams) == 20
+    assert ctypes.sizeof(_native.LaunchStats) == 20
+
+
+def test_search_without_gpu_fails_loudly():
+    if _native.device_count() > 0:
+        pytest.skip("a GPU is present")
+    off, comps, vals = random_dataset(1, 50, 32)
+    ix = _native.NativeIndex.build(2, 32, off, comps, vals)
+    with pytest.raises(_native.SeismicHipError) as e:
+        ix.upload(0)
+    assert e.value.status == 2   # SGPU_EDEVICE
+    with pytest.raises(_native.SeismicHipError) as e:   # not uploaded -> no silent CPU path
+        ix.search([1], [1.0], 10, 5, 0.7)
+    assert e.value.status == 2
+
+
+def test_desc_validation_rejects_corrupt_indexes():
+    off, comps, vals = random_dataset(2, 200, 64)
+    ix = _native.NativeIndex.build(2, 64, off, comps, vals, BuildConfig.defaults(n_postings=20))
+    a = orc.desc_arrays(ix.desc)
+    for field, mutate in [("post_doc", lambda x: x.__setitem__(0, 10 ** 6)),
+                          ("sum_bid", lambda x: x.__setitem__(0, 65535)),
+                          ("fwd_offsets", lambda x: x.__setitem__(1, 10 ** 9))]:
+        d = IndexDesc.from_buffer_copy(ix.desc)
+        arr = a[field].copy()
+        mutate(arr)
+        setattr(d, field, arr.ctypes.data_as(type(getattr(d, field))))
+        with pytest.raises(_native.SeismicHipError) as e:
+            _native.NativeIndex.from_desc(d)
+        assert e.value.status == 1
+
+
+def test_exact_search_matches_oracle_bruteforce():
+    dim = 200
+    off, comps, vals = random_dataset(3, 3000, dim, nnz_lo=5, nnz_hi=60)
+    ix = _native.NativeIndex.build(2, dim, off, comps, vals, BuildConfig.defaults(n_postings=10))
+    q_off, qc, qv = random_queries(4, 20, dim, 5, 40)
+    sc, ids, n = ix.exact_search(q_off, qc, qv, 10)
+    for i in range(20):
+        c = qc[q_off[i]:q_off[i + 1]]
+        v = qv[q_off[i]:q_off[i + 1]]
+        es, ei = orc.exact_search(ix.desc, c, v, 10, orc.ORDER_SEQ)
+        assert np.array_equal(ids[i, :n[i]], ei)
+        assert np.array_equal(sc[i, :n[i]].view(np.uint32), es.view(np.uint32))
+
+
+def test_resolve_query_tokens_semantics():
+    tm = {"a": 3, "b": 1, "c": 2}
+    c, v = _resolve(["a", "zzz", "b", "c"], [1.0, 9.0, 2.0, 3.0], tm)   # unknown dropped, sorted by id
+    assert c.tolist() == [1, 2, 3] and v.tolist() == [2.0, 3.0, 1.0]
+    assert seismic_amd.get_seismic_string() == "U30"
+
+
+def test_toy_dataset_plumbing_and_golden(tmp_path):
+    """BASELINE config 1: toy dataset indexed with the Python-default parameters; the oracle's
+    answers on the product-built index equal the committed golden file."""
+    import json
+    ix = seismic_amd.SeismicIndex.build(os.path.join(GOLD, "toy", "documents.jsonl"), upload=False)
+    exp = json.load(open(os.path.join(GOLD, "toy", "expected.json")))
+    assert (ix.dim, ix.len) == (exp["dim"], exp["n_docs"]) == (1396, 20)
+    assert ix.get_doc_ids_in_postings(0) is not None
+    ids, vecs, _ = seismic_amd.index.read_jsonl(os.path.join(GOLD, "toy", "queries.jsonl"))
+    for row, qv in zip(exp["queries"], vecs):
+        qc, qw = _resolve(list(qv.keys()), list(qv.values()), ix._tm)
+        for srt in (False, True):
+            s, i = orc.search(ix._ix.desc, qc, qw, 10, 10, 0.7, srt)
+            got = [[ix._doc_ids[int(x)], float(y)] for y, x in zip(s, i)]
+            assert got == row["seismic_sorted_%s" % srt]
+        # the empty document (id 18) is never retrieved
+        assert all(d != "18" for d, _ in row["seismic_sorted_True"])
+    # persistence of the string-keyed wrapper
+    ix.save(str(tmp_path / "toy"))
+    jx = seismic_amd.SeismicIndex.load(str(tmp_path / "toy"), upload=False)
+    assert jx._tm == ix._tm and jx._doc_ids == ix._doc_ids and jx.nnz == ix.nnz
+
+
+def test_golden_synth_small_oracle():
+    import json
+    g = json.load(open(os.path.join(GOLD, "synth_small.json")))
+    off, c, v = orc.csr([(d[0], d[1]) for d in g["docs"]])
+    for build in ("oracle", "product"):
+        if build == "oracle":
+            desc = orc.OracleIndex(2, g["dim"], off, c, v, BuildConfig.defaults(**g["build"]))
+            d = desc.desc
+        else:
+            ix = _native.NativeIndex.build(2, g["dim"], off, c, v, BuildConfig.defaults(**g["build"]))
+            d = ix.desc
+        for r in g["results"]:
+            for (qc, qv), e in zip(g["queries"], r["per_query"]):
+                s, i = orc.search(d, qc, qv, r["k"], r["query_cut"], r["heap_factor"], r["first_sorted"])
+                assert [int(x) for x in i] == e["ids"]
+                assert [int(x) for x in s.view(np.uint32)] == e["score_bits"]
+
+
+def test_inner_format_roundtrip(tmp_path):
+    off, comps, vals = random_dataset(5, 100, 500)
+    p = str(tmp_path / "documents.bin")
+    seismic_amd.write_inner_format(p, off, comps, vals)
+    o2, c2, v2 = seismic_amd.read_inner_format(p)
+    assert np.array_equal(off, o2) and np.array_equal(comps, c2) and np.array_equal(vals, v2)
+
+
+def test_seismic_dataset_exact_search():
+    ds = seismic_amd.SeismicDataset()
+    ds.add_document("d0", ["x", "y"], [1.0, 2.0])
+    ds.add_document("d1", ["y", "z"], [4.0, 5.0])
+    ds.add_document("d2", [], [])
+    assert ds.len == 3
+    r = ds.search("q", np.array(["y", "nope"], dtype="U30"), np.array([2.0, 1.0], np.float32), 2)
+    assert r == [("q", 8.0, "d1"), ("q", 4.0, "d0")]
+
+
+def test_score_order_tolerance():
+    """The canonical 16-lane accumulation order vs a plain left-to-right sum: the stated
+    tolerance |d| <= 1e-5 * max(1, |s|) (vectorium's true order is not in the reference tree)."""
+    dim = 300
+    off, comps, vals = random_dataset(6, 2000, dim, nnz_lo=50, nnz_hi=280)
+    ix = _native.NativeIndex.build(2, dim, off, comps, vals, BuildConfig.defaults(n_postings=5))
+    q_off, qc, qv = random_queries(7, 8, dim, 20, 90)
+    worst = 0.0
+    for i in range(8):
+        c = qc[q_off[i]:q_off[i + 1]]
+        v = qv[q_off[i]:q_off[i + 1]]
+        for doc in range(0, 2000, 37):
+            a = orc.score_doc(ix.desc, doc, c, v, orc.ORDER_LANES16)
+            b = orc.score_doc(ix.desc, doc, c, v, orc.ORDER_SEQ)
+            worst = max(worst, abs(a - b) / max(1.0, abs(b)))
+    assert worst <= 1e-5
