@@ -190,6 +190,12 @@ sgpu_status sgpu_batch_create(sgpu_index* idx, const uint64_t* q_off,
 sgpu_status sgpu_batch_run(sgpu_index* idx, sgpu_batch* batch,
                            const sgpu_search_params* params, int32_t sync,
                            sgpu_launch_stats* stats);
+/* Same search, synchronous, but with the reference's visited set materialised as a bitmap in HBM
+ * instead of the (exactly equivalent, cheaper) heap-membership test: results are identical, and
+ * work counters [5],[6] of sgpu_batch_fetch_stats then exclude re-encountered documents exactly
+ * as the reference's FxHashSet does (src/inverted_index.rs:181-184). Used for accounting. */
+sgpu_status sgpu_batch_run_counted(sgpu_index* idx, sgpu_batch* batch,
+                                   const sgpu_search_params* params, sgpu_launch_stats* stats);
 /* Blocks until all enqueued passes are done; *stats (may be NULL) gets the MEAN
  * kernel duration of the passes enqueued since the previous sync. */
 sgpu_status sgpu_batch_sync(sgpu_index* idx, sgpu_launch_stats* stats);
@@ -198,7 +204,8 @@ sgpu_status sgpu_batch_fetch(sgpu_index* idx, sgpu_batch* batch, uint32_t k,
 /* Work counters of the batch's LAST pass, nq x 24 uint32 per query:
  *   [0] blocks of the walked lists   [1] summary rows matched   [2] summary entries read
  *   [3] blocks that passed the skip test   [4] postings of those blocks
- *   [5] documents scored (as the reference would)   [6] sum of their component counts
+ *   [5] documents scored (as the reference would; exact after sgpu_batch_run_counted, otherwise
+ *       re-encountered documents are included)   [6] sum of their component counts
  *   [7] documents the kernel scored speculatively (>= [5]; the surplus is overhead)
  *   [8..19] kernel phase clocks (shader cycles / 16), [20] workgroup slot, [21..23] reserved
  * Counters [0..6] are what the ALGORITHM touches and feed the roofline accounting. */

@@ -13,7 +13,7 @@ from ._abi import (ABI_VERSION, BuildConfig, IndexDesc, LaunchStats, SearchParam
                    SGPU_OK)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libseismic_hip.so")
+LIB_PATH = os.environ.get("SGPU_LIB") or os.path.join(_HERE, "libseismic_hip.so")   # SGPU_LIB: experiment builds
 _lib = None
 
 
@@ -53,6 +53,7 @@ def lib():
         L.sgpu_batch_search.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp, vp]
         L.sgpu_batch_create.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.sgpu_batch_run.argtypes = [vp, vp, C.POINTER(SearchParams), C.c_int32, C.POINTER(LaunchStats)]
+        L.sgpu_batch_run_counted.argtypes = [vp, vp, C.POINTER(SearchParams), C.POINTER(LaunchStats)]
         L.sgpu_batch_sync.argtypes = [vp, C.POINTER(LaunchStats)]
         L.sgpu_batch_fetch.argtypes = [vp, vp, C.c_uint32, vp, vp, vp]
         L.sgpu_batch_fetch_stats.argtypes = [vp, vp, vp]
@@ -210,6 +211,13 @@ class DeviceBatch:
         p = params(k, query_cut, heap_factor, first_sorted)
         st = LaunchStats()
         check(lib().sgpu_batch_run(self.index.h, self.h, C.byref(p), 1 if sync else 0, C.byref(st)))
+        return st
+
+    def run_counted(self, k, query_cut, heap_factor, first_sorted=False):
+        """Synchronous pass with the visited bitmap: identical results, exact work counters."""
+        p = params(k, query_cut, heap_factor, first_sorted)
+        st = LaunchStats()
+        check(lib().sgpu_batch_run_counted(self.index.h, self.h, C.byref(p), C.byref(st)))
         return st
 
     def sync(self):

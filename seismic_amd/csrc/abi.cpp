@@ -122,6 +122,12 @@ sgpu_status sgpu_batch_run(sgpu_index* idx, sgpu_batch* batch, const sgpu_search
   return batch_run(idx->dev, batch, *params, 0 /*MODE_SEARCH*/, sync, stats);
 }
 
+sgpu_status sgpu_batch_run_counted(sgpu_index* idx, sgpu_batch* batch, const sgpu_search_params* params,
+                                   sgpu_launch_stats* stats) {
+  if (!idx || !batch || !params) return fail(SGPU_EINVAL, "null argument");
+  return batch_run(idx->dev, batch, *params, 2 /*MODE_COUNTED*/, 1, stats);
+}
+
 sgpu_status sgpu_batch_sync(sgpu_index* idx, sgpu_launch_stats* stats) {
   if (!idx) return fail(SGPU_EINVAL, "null argument");
   return batch_sync(idx->dev, stats);

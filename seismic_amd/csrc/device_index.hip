@@ -365,6 +365,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   const uint32_t NT = env_u32("SGPU_BLOCK", 512);
   if (NT != 256 && NT != 512 && NT != 1024) return fail(SGPU_EINVAL, "SGPU_BLOCK must be 256, 512 or 1024");
   const uint32_t qn = std::max<uint32_t>(4, (b->max_nnz + 3u) & ~3u);
+  const bool searching = mode != MODE_DOTS;
   const uint32_t qc = std::max<uint32_t>(1, std::min<uint32_t>(mode == MODE_DOTS ? 1u : sp.query_cut, qn));
   const uint32_t words = (d->view.dim + 31) / 32;
   const uint32_t items_max = env_u32("SGPU_ITEMS_MAX", 1024);
@@ -390,13 +391,13 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   L.rt_start = o; o += up16(qc * qn * 4);
   L.rt_pre = o; o += up16(qc * (qn + 1) * 4);
   L.dots = o; o += up16(dots_cap * 4);
-  L.order = o; o += up16((sp.first_sorted && mode == MODE_SEARCH) ? sort_nb * 2 : 0);
+  L.order = o; o += up16((sp.first_sorted && searching) ? sort_nb * 2 : 0);
   L.part = o; o += up16((NT / 64 + 1) * 4);
   L.st = o; o += up16(8 * 4);
   L.uni = o;
   const uint32_t chunk_bytes = items_max * 18 + NT * 12;
   uint32_t sort_bytes = 0;
-  if (sp.first_sorted && mode == MODE_SEARCH && sort_nb > 1) {
+  if (sp.first_sorted && searching && sort_nb > 1) {
     uint32_t n2 = 1;
     while (n2 < sort_nb) n2 <<= 1;
     sort_bytes = n2 * 8;
@@ -424,7 +425,8 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   a->p.query_cut = qc;
   a->p.heap_factor = sp.heap_factor;
   a->p.first_sorted = sp.first_sorted != 0;
-  a->p.mode = mode;
+  a->p.mode = mode == MODE_COUNTED ? (uint32_t)MODE_SEARCH : mode;
+  a->p.use_bitmap = (mode == MODE_COUNTED || env_u32("SGPU_VISITED_BITMAP", 0)) ? 1u : 0u;
   a->p.stage_cap = uni / 8;
   a->p.items_max = items_max;
   a->p.items_init = std::min<uint32_t>(items_max, env_u32("SGPU_ITEMS_INIT", 128));
@@ -445,7 +447,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   a->qb.out_ids = b->out_ids;
   a->qb.out_n = b->out_n;
   a->qb.q_order = d_order;
-  a->qb.out_stats = mode == MODE_SEARCH ? b->out_stats : nullptr;
+  a->qb.out_stats = mode != MODE_DOTS ? b->out_stats : nullptr;
   int per_cu = 0;
   HIP_TRY(occupancy_search(*a, &per_cu));
   if (per_cu < 1) return fail(SGPU_ELIMIT, "the search kernel does not fit on a CU with %u bytes of LDS", o);
@@ -455,7 +457,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
   a->grid = grid;
   // visited bitmaps: one per resident workgroup
-  if (d->bitmaps_slots < grid) {
+  if (a->p.use_bitmap && d->bitmaps_slots < grid) {
     if (d->bitmaps) (void)hipFree(d->bitmaps);
     d->bitmaps = nullptr;
     d->bitmaps_slots = 0;

@@ -37,7 +37,7 @@ struct BatchView {
   uint32_t* out_stats;     // optional nq x STATS_WORDS counters (zeroed by the host before a pass)
 };
 
-enum { MODE_SEARCH = 0, MODE_DOTS = 1 };
+enum { MODE_SEARCH = 0, MODE_DOTS = 1, MODE_COUNTED = 2 };   // COUNTED: search with the visited bitmap (exact counters)
 enum { STATS_WORDS = 24 };   // per-query stats: 8 work counters + 12 phase clocks (>>4) + slot + pad
 
 struct KParams {
@@ -50,6 +50,7 @@ struct KParams {
   uint32_t items_init;   // first round's budget; adapts to the replay's keep ratio
   uint32_t items_min;    // lower bound of the budget
   uint32_t rblocks_max;  // blocks filtered per thread and round
+  uint32_t use_bitmap;   // 1: visited bitmap in HBM (exact work counters); 0: heap-membership dedup
   uint32_t target_list;  // MODE_DOTS: the posting list whose summary dots are wanted
 };
 

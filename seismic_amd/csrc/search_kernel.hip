@@ -52,6 +52,12 @@
 namespace sgpu {
 
 #define SGPU_DEV __device__ __forceinline__
+#ifndef SGPU_WAVES_PER_EU
+#define SGPU_WAVES_PER_EU 4   // 2 workgroups of 512 threads per CU (<= 128 VGPRs)
+#endif
+#ifndef SGPU_DU
+#define SGPU_DU 2             // documents in flight per 16-lane group in phase B
+#endif
 
 // ---------------------------------------------------------------------------
 // small helpers
@@ -548,10 +554,32 @@ struct WorkCount {
   uint32_t blocks, posts, docs, len;
 };
 
-// Sequential replay of the reference's decisions over the chunk's items (wavefront 0 only).
+// Is document `d` (wave-uniform) currently in the heap?
 template <int KR>
-SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, const float* dots, uint32_t n_items,
-                           uint32_t k, float heap_factor, uint32_t* bitmap, uint32_t& decided_blk,
+SGPU_DEV bool heap_contains(const RegHeap<KR>& heap, uint32_t d) {
+  bool m = false;
+#pragma unroll
+  for (int r = 0; r < KR; ++r) m |= __ballot(heap.doc[r] == d) != 0ull;
+  return m;
+}
+
+// Sequential replay of the reference's decisions over the chunk's items (wavefront 0 only).
+//
+// Visited set (reference: FxHashSet keyed by the document's forward-index offset,
+// src/inverted_index.rs:181-184, src/posting_list.rs:200,209). A document can recur only in a
+// LATER list of the same query (a list holds a document once). USE_BITMAP = true keeps a
+// per-workgroup bitmap in HBM (exact work counters; ~0.8 MB of extra traffic per query).
+// USE_BITMAP = false needs no visited set at all and is exactly equivalent: a recurring document
+// d has the same score s as the first time, and
+//   * while the heap is not full every visited document is in the heap, so membership == visited;
+//   * once full, a push is attempted only if s > kth. The first visit pushed d (then-kth <= kth < s)
+//     and d cannot have been evicted while s > kth, so d is still in the heap: membership == visited
+//     for exactly the items whose push would change anything. Recurring documents with s <= kth
+//     are rejected by the reference's visited test and by the push rule alike.
+// The price is re-scoring the recurring documents (1-2% of the postings).
+template <int KR, bool USE_BITMAP>
+SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_items, uint32_t k,
+                           float heap_factor, uint32_t* bitmap, uint32_t& decided_blk,
                            bool block_starts_at_0, WorkCount& wc, uint32_t& live_items) {
   const uint32_t lane = lane_id();
   const uint32_t* it_words = (const uint32_t*)cb.it_ref;   // [2i] = low ref word (len), [2i+1] = score
@@ -575,6 +603,13 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, const float* 
     }
     if (heap.len < k) {
       // heap not full: every block that starts now is evaluated, every new doc is pushed
+      if (!USE_BITMAP) {   // visited == already in the heap
+#pragma unroll
+        for (int r = 0; r < KR; ++r) {
+          const uint32_t lim = heap.len > (uint32_t)r * 64u ? heap.len - (uint32_t)r * 64u : 0u;
+          for (uint32_t l = 0; l < (lim < 64u ? lim : 64u); ++l) vis |= doc == readlane_u(heap.doc[r], l);
+        }
+      }
       const uint64_t nvm = __ballot(valid && !vis);
       const uint32_t need = k - heap.len;
       const uint32_t before = (uint32_t)__popcll(nvm & ((1ull << lane) - 1ull));
@@ -584,7 +619,7 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, const float* 
       if ((uint32_t)__popcll(nvm) >= need) last = 63u - (uint32_t)__clzll(tm);
       else last = (n_items - i < 64u ? n_items - i : 64u) - 1u;
       if (take) {
-        visited_mark(bitmap, doc);
+        if (USE_BITMAP) visited_mark(bitmap, doc);
         wc.docs += 1;
         wc.len += len;
       }
@@ -607,15 +642,22 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, const float* 
     const float cut = __fmul_rn(heap_factor, thr);
     const bool live = valid && ((blk == decided_blk) || !(bdot < cut));
     const bool changing = live && !vis && (sc > thr);
-    const uint64_t cm = __ballot(changing);
+    uint64_t cm = __ballot(changing);
+    if (!USE_BITMAP) {   // drop recurring documents: they are in the heap already
+      while (cm) {
+        const uint32_t c0 = (uint32_t)(__ffsll((long long)cm) - 1);
+        if (!heap_contains<KR>(heap, readlane_u(doc, c0))) break;
+        cm &= cm - 1;
+      }
+    }
     const uint32_t f = cm ? (uint32_t)(__ffsll((long long)cm) - 1) : 63u;
     live_items += (uint32_t)__popcll(__ballot(live && lane <= f));
     if (live && lane <= f) {
       wc.posts += 1;
       wc.blocks += first;
       if (!vis) {
-        visited_mark(bitmap, doc);
-        wc.docs += 1;
+        if (USE_BITMAP) visited_mark(bitmap, doc);
+        wc.docs += 1;   // without the bitmap this also counts recurring documents that were rejected
         wc.len += len;
       }
     }
@@ -633,7 +675,7 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, const float* 
 // the kernel
 // ---------------------------------------------------------------------------
 template <typename CT, int NT, int KR>
-__global__ __launch_bounds__(NT, 4) void seismic_search_kernel(DevView ix, BatchView qb, KParams p,
+__global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(DevView ix, BatchView qb, KParams p,
                                                            LdsLayout L, uint32_t* queue,
                                                            uint32_t* bitmaps) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -828,7 +870,7 @@ __global__ __launch_bounds__(NT, 4) void seismic_search_kernel(DevView ix, Batch
               const uint32_t pidx = cb.cb_p0[lo] + (gi - excl);
               const uint32_t doc = ix.post_doc[pidx];
               const uint64_t ref = ix.post_ref[pidx];
-              const uint32_t vis = visited_test(bitmap, doc) ? 0x80000000u : 0u;
+              const uint32_t vis = (p.use_bitmap && visited_test(bitmap, doc)) ? 0x80000000u : 0u;
               cb.it_ref[i] = ref;
               cb.it_doc[i] = doc | vis;
               const uint32_t blk = cb.cb_blk[lo];
@@ -837,47 +879,45 @@ __global__ __launch_bounds__(NT, 4) void seismic_search_kernel(DevView ix, Batch
             }
             __syncthreads();
             TICK(6);
-            // (d) phase B: speculative scoring, 16 lanes per document, two documents in flight
+            // (d) phase B: speculative scoring, 16 lanes per document, DU documents in flight per group
             {
               const uint32_t grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
               constexpr uint32_t G = NT / 16;
+              constexpr int DU = SGPU_DU;
               float* it_score = (float*)cb.it_ref;
-              for (uint32_t i = grp; i < n_items; i += 2 * G) {
-                const uint32_t i1 = i + G;
-                const bool has1 = i1 < n_items;
-                const uint64_t ref0 = cb.it_ref[i];
-                const uint64_t ref1 = has1 ? cb.it_ref[i1] : 0ull;
-                const bool do0 = (cb.it_doc[i] >> 31) == 0;
-                const bool do1 = has1 && (cb.it_doc[i1] >> 31) == 0;
-                const uint32_t len0 = do0 ? (uint32_t)(ref0 & 0xffffu) : 0u;
-                const uint32_t len1 = do1 ? (uint32_t)(ref1 & 0xffffu) : 0u;
-                const uint8_t* rec0 = ix.fwd + (ref0 >> 16) * 16ull;
-                const uint8_t* rec1 = ix.fwd + (ref1 >> 16) * 16ull;
-                const uint8_t* val0 = rec0 + (size_t)((len0 + 7u) & ~7u) * sizeof(CT);
-                const uint8_t* val1 = rec1 + (size_t)((len1 + 7u) & ~7u) * sizeof(CT);
-                const uint32_t e0 = sub * 8u;
-                DocChunk<CT> d0, d1;
-                d0.c0 = d0.c1 = d0.v = make_uint4(0, 0, 0, 0);
-                d1 = d0;
-                if (e0 < len0) load_chunk<CT>(d0, rec0, val0, e0);
-                if (e0 < len1) load_chunk<CT>(d1, rec1, val1, e0);
-                float a0 = 0.0f, a1 = 0.0f;
-                if (e0 < len0) a0 = accumulate_chunk<CT>(s, d0, e0, len0, L.qn, a0);
-                if (e0 < len1) a1 = accumulate_chunk<CT>(s, d1, e0, len1, L.qn, a1);
-                for (uint32_t e = e0 + 128u; e < len0; e += 128u) {   // documents longer than 128
-                  load_chunk<CT>(d0, rec0, val0, e);
-                  a0 = accumulate_chunk<CT>(s, d0, e, len0, L.qn, a0);
+              const uint32_t e0 = sub * 8u;
+              for (uint32_t i = grp; i < n_items; i += DU * G) {
+                uint32_t len[DU];
+                const uint8_t* rec[DU];
+                const uint8_t* val[DU];
+                DocChunk<CT> d[DU];
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                  const uint32_t iu = i + (uint32_t)u * G;
+                  const bool has = iu < n_items;
+                  const uint64_t ref = has ? cb.it_ref[iu] : 0ull;
+                  const bool run = has && (cb.it_doc[has ? iu : 0] >> 31) == 0;
+                  len[u] = run ? (uint32_t)(ref & 0xffffu) : 0u;
+                  rec[u] = ix.fwd + (ref >> 16) * 16ull;
+                  val[u] = rec[u] + (size_t)((len[u] + 7u) & ~7u) * sizeof(CT);
                 }
-                for (uint32_t e = e0 + 128u; e < len1; e += 128u) {
-                  load_chunk<CT>(d1, rec1, val1, e);
-                  a1 = accumulate_chunk<CT>(s, d1, e, len1, L.qn, a1);
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                  d[u].c0 = d[u].c1 = d[u].v = make_uint4(0, 0, 0, 0);
+                  if (e0 < len[u]) load_chunk<CT>(d[u], rec[u], val[u], e0);
                 }
-                a0 = reduce16(a0);
-                a1 = reduce16(a1);
-                spec_docs += (sub == 0 && do0) + (sub == 0 && do1);
-                if (sub == 0) {
-                  it_score[2 * i + 1] = a0;
-                  if (has1) it_score[2 * i1 + 1] = a1;
+#pragma unroll
+                for (int u = 0; u < DU; ++u) {
+                  float a = 0.0f;
+                  if (e0 < len[u]) a = accumulate_chunk<CT>(s, d[u], e0, len[u], L.qn, a);
+                  for (uint32_t e = e0 + 128u; e < len[u]; e += 128u) {   // documents longer than 128
+                    load_chunk<CT>(d[u], rec[u], val[u], e);
+                    a = accumulate_chunk<CT>(s, d[u], e, len[u], L.qn, a);
+                  }
+                  a = reduce16(a);
+                  const uint32_t iu = i + (uint32_t)u * G;
+                  spec_docs += (sub == 0 && len[u] != 0);
+                  if (sub == 0 && iu < n_items) it_score[2 * iu + 1] = a;
                 }
               }
             }
@@ -886,8 +926,12 @@ __global__ __launch_bounds__(NT, 4) void seismic_search_kernel(DevView ix, Batch
             // (e) exact replay on wavefront 0
             if (wave == 0) {
               uint32_t live_items = 0;
-              replay_chunk<KR>(heap, cb, dots, n_items, p.k, p.heap_factor, bitmap, decided_blk, piece == 0, wc,
-                               live_items);
+              if (p.use_bitmap)
+                replay_chunk<KR, true>(heap, cb, n_items, p.k, p.heap_factor, bitmap, decided_blk, piece == 0, wc,
+                                       live_items);
+              else
+                replay_chunk<KR, false>(heap, cb, n_items, p.k, p.heap_factor, bitmap, decided_blk, piece == 0, wc,
+                                        live_items);
               if (lane == 0) {
                 s.st[ST_HLEN] = heap.len;
                 s.st[ST_THR] = __float_as_uint(heap.len == p.k ? heap.thr : 0.0f);
@@ -948,7 +992,8 @@ __global__ __launch_bounds__(NT, 4) void seismic_search_kernel(DevView ix, Batch
     }
     TICK(9);
     // ---- per-query cleanup: visited bitmap, query bits ----
-    for (uint32_t i = threadIdx.x; i < ix.n_bitmap_words; i += NT) bitmap[i] = 0;
+    if (p.use_bitmap)
+      for (uint32_t i = threadIdx.x; i < ix.n_bitmap_words; i += NT) bitmap[i] = 0;
     clear_query_bits<NT>(s, nnz);
     __threadfence_block();
     __syncthreads();

@@ -63,6 +63,7 @@ def test_golden_synth_small_on_gpu():
     dict(SGPU_BLOCK="256"),
     dict(SGPU_BLOCK="1024", SGPU_STAGE_BYTES="8192"),                                        # many staging windows
     dict(SGPU_NO_LPT="1", SGPU_ITEMS_INIT="1024"),
+    dict(SGPU_VISITED_BITMAP="1"),
 ])
 def test_kernel_paths_under_forced_small_buffers(env, monkeypatch):
     for k_, v_ in env.items():
@@ -104,8 +105,10 @@ def test_full_size_config_properties():
     ix.upload(0)
     q = _native.synth(nq, dim, 43, 1, docs)
     b = _native.DeviceBatch(ix, *q, 10)
-    b.run(10, 4, 1.0, False)
+    b.run(10, 4, 1.0, False)                  # default path: heap-membership dedup, no visited bitmap
     g1 = b.fetch(10)
+    b.run_counted(10, 4, 1.0, False)          # visited bitmap materialised: identical results, exact counters
+    _same(g1, b.fetch(10))
     kernel_bytes, counters = b.algorithmic_bytes(10, 2)
     sc, ids, n, st, _, _ = orc.batch_search(ix.desc, *q, 10, 4, 1.0, False)
     _same(g1, (sc, ids, n))

@@ -63,3 +63,21 @@ print("work/query: blocks %.0f rows %.0f entries %.0f | scored blocks %.0f posti
 slots = st[:, 20].astype(int)
 per_slot = np.bincount(slots, weights=tot)
 print("slots used %d, busiest slot %.1f us, mean %.1f us" % ((per_slot > 0).sum(), per_slot.max() / 2100, per_slot[per_slot > 0].mean() / 2100))
+# distribution of per-query cost and how well the a-priori proxy (postings of the walked lists) predicts it
+docs_q = st[:, 5]
+pct = [50, 90, 99, 100]
+print("docs/query percentiles %s: %s" % (pct, [int(np.percentile(docs_q, p)) for p in pct]))
+print("cycles/query percentiles %s: %s" % (pct, [int(np.percentile(tot, p)) for p in pct]))
+print("phaseB share of the 10 longest queries: %.2f" % (cyc[np.argsort(tot)[-10:], 7].sum() / tot[np.argsort(tot)[-10:]].sum()))
+q_off, qc, qv = q
+a_ = ix.desc
+lbs = np.ctypeslib.as_array(a_.list_block_start, shape=(a_.dim + 1,)).astype(np.int64)
+bps = np.ctypeslib.as_array(a_.block_post_start, shape=(a_.n_blocks + 1,)).astype(np.int64)
+npost = bps[lbs[1:]] - bps[lbs[:-1]]
+proxy = np.zeros(a.queries)
+for i in range(a.queries):
+    c = qc[q_off[i]:q_off[i + 1]]
+    v = qv[q_off[i]:q_off[i + 1]]
+    top = c[np.argsort(-v, kind="stable")[: a.query_cut]]
+    proxy[i] = npost[top].sum()
+print("corr(proxy, cycles) = %.3f, corr(docs, cycles) = %.3f" % (np.corrcoef(proxy, tot)[0, 1], np.corrcoef(docs_q, tot)[0, 1]))
