@@ -131,6 +131,14 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       uint8_t* rec = fwd.data() + rec_off16[(size_t)doc] * 16;
       std::memcpy(rec, h.fwd_comps.data() + s0 * cw, len * cw);
       std::memcpy(rec + npad * cw, h.fwd_vals.data() + s0, len * 2);
+      // padding components carry the sentinel id `dim` (never a query component) when it is
+      // representable; their values are 0. The dense lookup path relies on it, the bitmap path
+      // tests the length instead.
+      if (cw == 2 && h.dim <= 65535) {
+        for (uint64_t e = len; e < npad; ++e) ((uint16_t*)rec)[e] = (uint16_t)h.dim;
+      } else if (cw == 4) {
+        for (uint64_t e = len; e < npad; ++e) ((uint32_t*)rec)[e] = (uint32_t)h.dim;
+      }
     }
     if ((st = dev_copy(d, fwd.data(), fwd.size(), &d->view.fwd)) != SGPU_OK) return bail(st);
     fwd.clear();
@@ -363,7 +371,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   if (sp.n_knn != 0) return fail(SGPU_EINVAL, "n_knn must be 0: no kNN graph on this path");
   if (std::isnan(sp.heap_factor)) return fail(SGPU_EINVAL, "heap_factor is NaN");
   const uint32_t NT = env_u32("SGPU_BLOCK", 512);
-  if (NT != 256 && NT != 512 && NT != 1024) return fail(SGPU_EINVAL, "SGPU_BLOCK must be 256, 512 or 1024");
+  if (NT != 512 && NT != 1024) return fail(SGPU_EINVAL, "SGPU_BLOCK must be 512 or 1024");
   const uint32_t qn = std::max<uint32_t>(4, (b->max_nnz + 3u) & ~3u);
   const bool searching = mode != MODE_DOTS;
   const uint32_t qc = std::max<uint32_t>(1, std::min<uint32_t>(mode == MODE_DOTS ? 1u : sp.query_cut, qn));
@@ -385,7 +393,13 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   uint32_t o = 0;
   L.q_comp = o; o += up16(qn * 4);
   L.q_val = o; o += up16((qn + 1) * 4);   // + the 0.0 slot non-matching components resolve to
-  L.q_bits = o; o += up16(words * 8);   // {bits, rank} per 32 vocabulary ids
+  // query lookup table: dense u8 index (1 B per vocabulary id + the padding sentinel) when it is
+  // allowed and fits next to everything else at 2 workgroups per CU, else {bits, rank} per 32 ids
+  const bool dense_ok = d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255 &&
+                        !env_u32("SGPU_NO_DENSE", 0) && searching;
+  const uint32_t dense_bytes = up16(d->view.dim + 1), bitmap_bytes = up16(words * 8);
+  const uint32_t o_lookup = o;
+  L.q_bits = o; o += bitmap_bytes;
   L.q_rank = o;
   L.sel = o; o += up16((6 * qc + 1) * 4);
   L.rt_start = o; o += up16(qc * qn * 4);
@@ -414,6 +428,24 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   o += uni;
   L.qc = qc;
   L.qn = qn;
+  bool dense = false;
+  if (dense_ok && dense_bytes > bitmap_bytes) {
+    const uint32_t extra = dense_bytes - bitmap_bytes;
+    const uint32_t min_uni = up16(std::max(std::max(chunk_bytes, sort_bytes), qc * 128u * 8u));
+    const uint32_t budget = 160u * 1024u / 2u;   // keep 2 workgroups per CU
+    if (L.uni + extra + min_uni <= budget || env_u32("SGPU_FORCE_DENSE", 0)) {
+      dense = true;
+      // shift every region after the lookup table, shrink the union region if it was padded to the target
+      uint32_t* offs[] = {&L.q_rank, &L.sel, &L.rt_start, &L.rt_pre, &L.dots, &L.order, &L.part, &L.st, &L.uni};
+      for (uint32_t* po : offs) *po += extra;
+      uint32_t new_uni = uni;
+      if (L.uni + new_uni > budget) new_uni = std::max(min_uni, budget > L.uni ? (budget - L.uni) & ~15u : min_uni);
+      o = L.uni + new_uni;
+      a->p.stage_cap = new_uni / 8;
+    }
+  }
+  (void)o_lookup;
+  a->dense = dense ? 1u : 0u;
   L.total = o;
   if (o > lds_limit)
     return fail(SGPU_ELIMIT,
@@ -427,7 +459,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   a->p.first_sorted = sp.first_sorted != 0;
   a->p.mode = mode == MODE_COUNTED ? (uint32_t)MODE_SEARCH : mode;
   a->p.use_bitmap = (mode == MODE_COUNTED || env_u32("SGPU_VISITED_BITMAP", 0)) ? 1u : 0u;
-  a->p.stage_cap = uni / 8;
+  if (!dense) a->p.stage_cap = uni / 8;
   a->p.items_max = items_max;
   a->p.items_init = std::min<uint32_t>(items_max, env_u32("SGPU_ITEMS_INIT", 128));
   a->p.items_min = std::min<uint32_t>(a->p.items_init, env_u32("SGPU_ITEMS_MIN", 64));

@@ -68,6 +68,7 @@ struct LaunchArgs {
   uint32_t* queue;
   uint32_t* bitmaps;
   uint32_t comp_width, grid, block, lds_bytes;
+  uint32_t dense;   // 1: dense u8 query index in LDS (u16 components, dim <= 65535, query <= 255 components)
   hipStream_t stream;
 };
 

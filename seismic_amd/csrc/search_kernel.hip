@@ -119,7 +119,8 @@ SGPU_DEV uint32_t wg_inclusive_scan(uint32_t v, uint32_t* part, uint32_t* total)
 struct Lds {
   uint32_t* q_comp;
   float* q_val;
-  uint2* q_word;        // [ceil(dim/32)] {32 vocabulary bits, rank of the word's first query component}
+  uint2* q_word;        // bitmap mode: [ceil(dim/32)] {32 vocabulary bits, rank of the word's first query component}
+  uint8_t* q_idx;       // dense mode (same LDS region): [dim] 1 + rank of the component in the query, 0 = absent
   uint32_t* sel_comp;   // [QC] list (component) ids in traversal order
   uint32_t* sel_nb;     // [QC] blocks in the list
   uint32_t* sel_b0;     // [QC] first global block id
@@ -139,8 +140,9 @@ enum { ST_Q = 0, ST_NLISTS = 1, ST_THR = 2, ST_HLEN = 3, ST_TMP0 = 4, ST_TMP1 = 
 SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
   Lds l;
   l.q_comp = (uint32_t*)(smem + L.q_comp);
-  l.q_val = (float*)(smem + L.q_val);
+  l.q_val = (float*)(smem + L.q_val) + 1;   // q_val[-1] is the 0.0 every non-matching component resolves to
   l.q_word = (uint2*)(smem + L.q_bits);
+  l.q_idx = smem + L.q_bits;
   l.sel_comp = (uint32_t*)(smem + L.sel);
   l.sel_nb = l.sel_comp + L.qc;
   l.sel_b0 = l.sel_nb + L.qc;
@@ -160,7 +162,7 @@ SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
 // ---------------------------------------------------------------------------
 // stage 0: query into LDS, choose the lists
 // ---------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool DENSE>
 SGPU_DEV void load_query(const Lds& s, const BatchView& qb, uint32_t q, uint32_t* nnz_out) {
   const uint32_t o0 = qb.q_off[q], o1 = qb.q_off[q + 1];
   const uint32_t nnz = o1 - o0;
@@ -168,16 +170,23 @@ SGPU_DEV void load_query(const Lds& s, const BatchView& qb, uint32_t q, uint32_t
     const uint32_t c = qb.q_comp[o0 + j];
     s.q_comp[j] = c;
     s.q_val[j] = qb.q_val[o0 + j];
-    atomicOr(&s.q_word[c >> 5].x, 1u << (c & 31));
-    // rank of the first query component of each vocabulary word
-    if (j == 0 || (qb.q_comp[o0 + j - 1] >> 5) != (c >> 5)) s.q_word[c >> 5].y = j;
+    if (DENSE) {
+      s.q_idx[c] = (uint8_t)(j + 1);
+    } else {
+      atomicOr(&s.q_word[c >> 5].x, 1u << (c & 31));
+      // rank of the first query component of each vocabulary word
+      if (j == 0 || (qb.q_comp[o0 + j - 1] >> 5) != (c >> 5)) s.q_word[c >> 5].y = j;
+    }
   }
   *nnz_out = nnz;
 }
 
-template <int NT>
+template <int NT, bool DENSE>
 SGPU_DEV void clear_query_bits(const Lds& s, uint32_t nnz) {
-  for (uint32_t j = threadIdx.x; j < nnz; j += NT) s.q_word[s.q_comp[j] >> 5].x = 0;
+  for (uint32_t j = threadIdx.x; j < nnz; j += NT) {
+    if (DENSE) s.q_idx[s.q_comp[j]] = 0;
+    else s.q_word[s.q_comp[j] >> 5].x = 0;
+  }
 }
 
 // k_largest_by(query_cut, total_cmp) in descending order; ties: ascending component.
@@ -510,9 +519,8 @@ SGPU_DEV void load_chunk(DocChunk<CT>& d, const uint8_t* rec, const uint8_t* val
   d.v = *(const uint4*)(vals + (size_t)e0 * 2);
 }
 
-template <typename CT>
-SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0, uint32_t len, uint32_t qn,
-                                float acc) {
+template <typename CT, bool DENSE>
+SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0, uint32_t len, float acc) {
   uint32_t c[8];
   if (sizeof(CT) == 2) {
     c[0] = d.c0.x & 0xffffu; c[1] = d.c0.x >> 16; c[2] = d.c0.y & 0xffffu; c[3] = d.c0.y >> 16;
@@ -522,19 +530,29 @@ SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0
     c[4] = d.c1.x; c[5] = d.c1.y; c[6] = d.c1.z; c[7] = d.c1.w;
   }
   const uint32_t v[4] = {d.v.x, d.v.y, d.v.z, d.v.w};
-  uint2 w[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) w[i] = s.q_word[c[i] >> 5];
-  uint32_t r[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint32_t bit = c[i] & 31u;
-    const bool hit = ((w[i].x >> bit) & 1u) && (e0 + (uint32_t)i < len);
-    r[i] = hit ? w[i].y + (uint32_t)__popc(w[i].x & ((1u << bit) - 1u)) : qn;
-  }
   float qv[8];
+  if (DENSE) {
+    // one byte per vocabulary id: 1 + rank in the query, 0 = absent (-> q_val[-1] == 0.0).
+    // Padding components carry the sentinel id `dim`, whose byte is always 0: no length test.
+    uint32_t r[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) qv[i] = s.q_val[r[i]];
+    for (int i = 0; i < 8; ++i) r[i] = s.q_idx[c[i]];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = s.q_val[(int)r[i] - 1];
+  } else {
+    uint2 w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = s.q_word[c[i] >> 5];
+    int r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t bit = c[i] & 31u;
+      const bool hit = ((w[i].x >> bit) & 1u) && (e0 + (uint32_t)i < len);
+      r[i] = hit ? (int)(w[i].y + (uint32_t)__popc(w[i].x & ((1u << bit) - 1u))) : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = s.q_val[r[i]];
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const float dv = half_bits_to_float((v[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
@@ -674,7 +692,7 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_it
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
-template <typename CT, int NT, int KR>
+template <typename CT, int NT, int KR, bool DENSE>
 __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(DevView ix, BatchView qb, KParams p,
                                                            LdsLayout L, uint32_t* queue,
                                                            uint32_t* bitmaps) {
@@ -687,8 +705,12 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
   WorkCount wc;       // lane-local partial counts, wavefront 0
 
   // one-time LDS init
-  for (uint32_t i = threadIdx.x; i < (ix.dim + 31) / 32; i += NT) s.q_word[i] = make_uint2(0u, 0u);
-  if (threadIdx.x == 0) s.q_val[L.qn] = 0.0f;   // the weight every non-matching component resolves to
+  {
+    uint32_t* z = (uint32_t*)(smem + L.q_bits);
+    const uint32_t nz = DENSE ? (ix.dim + 1 + 3) / 4 : 2 * ((ix.dim + 31) / 32);
+    for (uint32_t i = threadIdx.x; i < nz; i += NT) z[i] = 0;
+  }
+  if (threadIdx.x == 0) s.q_val[-1] = 0.0f;   // the weight every non-matching component resolves to
   __syncthreads();
 
   for (;;) {
@@ -714,7 +736,7 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
   }
     // ---- stage 0 ----
     uint32_t nnz;
-    load_query<NT>(s, qb, q, &nnz);
+    load_query<NT, DENSE>(s, qb, q, &nnz);
     heap.reset();
     wc = WorkCount{0, 0, 0, 0};
     uint32_t spec_docs = 0, st_entries = 0, st_rows = 0;
@@ -758,7 +780,7 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
         for (uint32_t i = threadIdx.x; i < s.sel_nb[0]; i += NT) qb.out_scores[i] = s.dots[i];
         if (threadIdx.x == 0) qb.out_n[q] = s.sel_nb[0];
         __syncthreads();
-        clear_query_bits<NT>(s, nnz);
+        clear_query_bits<NT, DENSE>(s, nnz);
         __syncthreads();
         continue;
       }
@@ -909,10 +931,10 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
 #pragma unroll
                 for (int u = 0; u < DU; ++u) {
                   float a = 0.0f;
-                  if (e0 < len[u]) a = accumulate_chunk<CT>(s, d[u], e0, len[u], L.qn, a);
+                  if (e0 < len[u]) a = accumulate_chunk<CT, DENSE>(s, d[u], e0, len[u], a);
                   for (uint32_t e = e0 + 128u; e < len[u]; e += 128u) {   // documents longer than 128
                     load_chunk<CT>(d[u], rec[u], val[u], e);
-                    a = accumulate_chunk<CT>(s, d[u], e, len[u], L.qn, a);
+                    a = accumulate_chunk<CT, DENSE>(s, d[u], e, len[u], a);
                   }
                   a = reduce16(a);
                   const uint32_t iu = i + (uint32_t)u * G;
@@ -994,7 +1016,7 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
     // ---- per-query cleanup: visited bitmap, query bits ----
     if (p.use_bitmap)
       for (uint32_t i = threadIdx.x; i < ix.n_bitmap_words; i += NT) bitmap[i] = 0;
-    clear_query_bits<NT>(s, nnz);
+    clear_query_bits<NT, DENSE>(s, nnz);
     __threadfence_block();
     __syncthreads();
     TICK(11);
@@ -1011,64 +1033,35 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
 // ---------------------------------------------------------------------------
 // host-callable launcher table
 // ---------------------------------------------------------------------------
-template <typename CT, int NT, int KR>
-static hipError_t launch_one(const LaunchArgs& a) {
-  auto kern = seismic_search_kernel<CT, NT, KR>;
+template <typename CT, int NT, int KR, bool DENSE>
+static hipError_t run_one(const LaunchArgs& a, int* occupancy) {
+  auto kern = seismic_search_kernel<CT, NT, KR, DENSE>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)a.lds_bytes);
   if (e != hipSuccess) return e;
+  if (occupancy) return hipOccupancyMaxActiveBlocksPerMultiprocessor(occupancy, kern, NT, a.lds_bytes);
   hipLaunchKernelGGL(kern, dim3(a.grid), dim3(NT), a.lds_bytes, a.stream, a.ix, a.qb, a.p, a.L, a.queue,
                      a.bitmaps);
   return hipGetLastError();
 }
 
-template <typename CT, int NT>
-static hipError_t launch_kr(const LaunchArgs& a) {
+template <typename CT, int NT, bool DENSE>
+static hipError_t run_kr(const LaunchArgs& a, int* occ) {
   const uint32_t k = a.p.k;
-  if (k <= 64) return launch_one<CT, NT, 1>(a);
-  if (k <= 128) return launch_one<CT, NT, 2>(a);
-  if (k <= 256) return launch_one<CT, NT, 4>(a);
-  if (k <= 512) return launch_one<CT, NT, 8>(a);
-  return launch_one<CT, NT, 16>(a);
+  if (k <= 64) return run_one<CT, NT, 1, DENSE>(a, occ);
+  if (k <= 128) return run_one<CT, NT, 2, DENSE>(a, occ);
+  return run_one<CT, NT, 16, DENSE>(a, occ);
 }
 
-template <typename CT, int NT, int KR>
-static hipError_t occ_one(const LaunchArgs& a, int* n) {
-  auto kern = seismic_search_kernel<CT, NT, KR>;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)a.lds_bytes);
-  if (e != hipSuccess) return e;
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(n, kern, NT, a.lds_bytes);
-}
-template <typename CT, int NT>
-static hipError_t occ_kr(const LaunchArgs& a, int* n) {
-  const uint32_t k = a.p.k;
-  if (k <= 64) return occ_one<CT, NT, 1>(a, n);
-  if (k <= 128) return occ_one<CT, NT, 2>(a, n);
-  if (k <= 256) return occ_one<CT, NT, 4>(a, n);
-  if (k <= 512) return occ_one<CT, NT, 8>(a, n);
-  return occ_one<CT, NT, 16>(a, n);
-}
-hipError_t occupancy_search(const LaunchArgs& a, int* n) {
+static hipError_t run_any(const LaunchArgs& a, int* occ) {
   if (a.comp_width == 2) {
-    if (a.block == 256) return occ_kr<uint16_t, 256>(a, n);
-    if (a.block == 1024) return occ_kr<uint16_t, 1024>(a, n);
-    return occ_kr<uint16_t, 512>(a, n);
+    if (a.dense) return a.block == 1024 ? run_kr<uint16_t, 1024, true>(a, occ) : run_kr<uint16_t, 512, true>(a, occ);
+    return a.block == 1024 ? run_kr<uint16_t, 1024, false>(a, occ) : run_kr<uint16_t, 512, false>(a, occ);
   }
-  if (a.block == 256) return occ_kr<uint32_t, 256>(a, n);
-  if (a.block == 1024) return occ_kr<uint32_t, 1024>(a, n);
-  return occ_kr<uint32_t, 512>(a, n);
+  return a.block == 1024 ? run_kr<uint32_t, 1024, false>(a, occ) : run_kr<uint32_t, 512, false>(a, occ);
 }
 
-hipError_t launch_search(const LaunchArgs& a) {
-  if (a.comp_width == 2) {
-    if (a.block == 256) return launch_kr<uint16_t, 256>(a);
-    if (a.block == 1024) return launch_kr<uint16_t, 1024>(a);
-    return launch_kr<uint16_t, 512>(a);
-  }
-  if (a.block == 256) return launch_kr<uint32_t, 256>(a);
-  if (a.block == 1024) return launch_kr<uint32_t, 1024>(a);
-  return launch_kr<uint32_t, 512>(a);
-}
+hipError_t occupancy_search(const LaunchArgs& a, int* n) { return run_any(a, n); }
+hipError_t launch_search(const LaunchArgs& a) { return run_any(a, nullptr); }
 
 }  // namespace sgpu

@@ -60,7 +60,7 @@ def test_golden_synth_small_on_gpu():
 
 @pytest.mark.parametrize("env", [
     dict(SGPU_ITEMS_MAX="64", SGPU_ITEMS_INIT="16", SGPU_ITEMS_MIN="16", SGPU_RBLOCKS="1"),   # many rounds, oversize blocks
-    dict(SGPU_BLOCK="256"),
+    dict(SGPU_NO_DENSE="1"),
     dict(SGPU_BLOCK="1024", SGPU_STAGE_BYTES="8192"),                                        # many staging windows
     dict(SGPU_NO_LPT="1", SGPU_ITEMS_INIT="1024"),
     dict(SGPU_VISITED_BITMAP="1"),
