@@ -171,17 +171,26 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       if ((st = dev_copy(d, v.data(), v.size(), &d->view.row_ptr)) != SGPU_OK) return bail(st);
     }
     {
-      std::vector<float2> mq(h.n_blocks());
-      for (size_t b = 0; b < mq.size(); ++b) mq[b] = make_float2(h.blk_min[b], h.blk_quant[b]);
-      if ((st = dev_copy(d, mq.data(), mq.size(), &d->view.blk_mq)) != SGPU_OK) return bail(st);
-    }
-    {
       const uint8_t* rc = nullptr;
       if ((st = dev_copy(d, h.row_comp.data(), h.row_comp.size(), &rc)) != SGPU_OK) return bail(st);
       d->view.row_comp = rc;
     }
     if ((st = dev_copy(d, h.sum_bid.data(), h.sum_bid.size(), &d->view.sum_bid)) != SGPU_OK) return bail(st);
-    if ((st = dev_copy(d, h.sum_code.data(), h.sum_code.size(), &d->view.sum_code)) != SGPU_OK) return bail(st);
+    {
+      // dequantised summary values: code*quant + min with the reference's two roundings
+      // (src/quantized_summary.rs:102-104; this file is compiled with -ffp-contract=off)
+      std::vector<float> deq(h.n_entries());
+      for (uint64_t c = 0; c < h.dim; ++c) {
+        const uint64_t b0 = h.list_block_start[c];
+        for (uint64_t r = h.list_row_start[c]; r < h.list_row_start[c + 1]; ++r)
+          for (uint64_t e = h.row_ptr[r]; e < h.row_ptr[r + 1]; ++e) {
+            const uint64_t blk = b0 + h.sum_bid[e];
+            const volatile float t = (float)h.sum_code[e] * h.blk_quant[blk];
+            deq[e] = t + h.blk_min[blk];
+          }
+      }
+      if ((st = dev_copy(d, deq.data(), deq.size(), &d->view.sum_deq)) != SGPU_OK) return bail(st);
+    }
     d->view.dim = (uint32_t)h.dim;
     d->view.n_docs = (uint32_t)h.n_docs;
     d->view.n_bitmap_words = (uint32_t)((h.n_docs + 31) / 32);
@@ -393,14 +402,6 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   uint32_t o = 0;
   L.q_comp = o; o += up16(qn * 4);
   L.q_val = o; o += up16((qn + 1) * 4);   // + the 0.0 slot non-matching components resolve to
-  // query lookup table: dense u8 index (1 B per vocabulary id + the padding sentinel) when it is
-  // allowed and fits next to everything else at 2 workgroups per CU, else {bits, rank} per 32 ids
-  const bool dense_ok = d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255 &&
-                        !env_u32("SGPU_NO_DENSE", 0) && searching;
-  const uint32_t dense_bytes = up16(d->view.dim + 1), bitmap_bytes = up16(words * 8);
-  const uint32_t o_lookup = o;
-  L.q_bits = o; o += bitmap_bytes;
-  L.q_rank = o;
   L.sel = o; o += up16((6 * qc + 1) * 4);
   L.rt_start = o; o += up16(qc * qn * 4);
   L.rt_pre = o; o += up16(qc * (qn + 1) * 4);
@@ -408,7 +409,8 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   L.order = o; o += up16((sp.first_sorted && searching) ? sort_nb * 2 : 0);
   L.part = o; o += up16((NT / 64 + 1) * 4);
   L.st = o; o += up16(8 * 4);
-  L.uni = o;
+  // [lookup table | union region]: stage 1 uses both as one staging area (the lookup table is
+  // built after stage 1); stage 2 uses the lookup table + the union region (sort keys, item tables).
   const uint32_t chunk_bytes = items_max * 18 + NT * 12;
   uint32_t sort_bytes = 0;
   if (sp.first_sorted && searching && sort_nb > 1) {
@@ -417,35 +419,29 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
     sort_bytes = n2 * 8;
   }
   const uint32_t lds_limit = std::min<uint32_t>(d->max_lds ? d->max_lds : 65536, 160 * 1024);
-  const uint32_t target = env_u32("SGPU_LDS_TARGET", 76 * 1024);   // 2 workgroups per CU (160 KiB / 2, minus rounding)
+  const uint32_t budget = env_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
+  const uint32_t min_uni = up16(std::max(chunk_bytes, sort_bytes));
+  // query lookup table: dense u8 index (1 B per vocabulary id + the padding sentinel) when it is
+  // allowed and fits at 2 workgroups per CU, else {bits, rank} per 32 vocabulary ids
+  const uint32_t dense_bytes = up16(d->view.dim + 1), bitmap_bytes = up16(words * 8);
+  const bool dense_ok = d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255 &&
+                        !env_u32("SGPU_NO_DENSE", 0) && searching;
+  const bool dense = dense_ok && (o + dense_bytes + min_uni <= budget || env_u32("SGPU_FORCE_DENSE", 0));
+  const uint32_t lookup_bytes = mode == MODE_DOTS ? 0u : (dense ? dense_bytes : bitmap_bytes);
+  L.q_bits = o; o += lookup_bytes;
+  L.q_rank = o;
+  L.uni = o;
+  uint32_t uni = min_uni;
+  const uint32_t min_stage = qc * 64u * 6u + 16u;
+  if (lookup_bytes + uni < min_stage) uni = up16(min_stage - lookup_bytes);
   uint32_t stage_bytes = env_u32("SGPU_STAGE_BYTES", 0);
-  if (!stage_bytes) {
-    stage_bytes = target > o + 8192 ? target - o : 8192;
-    stage_bytes = std::min<uint32_t>(stage_bytes, 64 * 1024);
-  }
-  stage_bytes = std::max<uint32_t>(stage_bytes, qc * 128 * 8);
-  const uint32_t uni = up16(std::max(std::max(chunk_bytes, sort_bytes), stage_bytes));
+  if (stage_bytes) uni = std::max(uni, up16(stage_bytes > lookup_bytes ? stage_bytes - lookup_bytes : 0u));
+  else if (o + uni < budget) uni = (budget - o) & ~15u;   // give stage 1 whatever is left at this occupancy
   o += uni;
   L.qc = qc;
   L.qn = qn;
-  bool dense = false;
-  if (dense_ok && dense_bytes > bitmap_bytes) {
-    const uint32_t extra = dense_bytes - bitmap_bytes;
-    const uint32_t min_uni = up16(std::max(std::max(chunk_bytes, sort_bytes), qc * 128u * 8u));
-    const uint32_t budget = 160u * 1024u / 2u;   // keep 2 workgroups per CU
-    if (L.uni + extra + min_uni <= budget || env_u32("SGPU_FORCE_DENSE", 0)) {
-      dense = true;
-      // shift every region after the lookup table, shrink the union region if it was padded to the target
-      uint32_t* offs[] = {&L.q_rank, &L.sel, &L.rt_start, &L.rt_pre, &L.dots, &L.order, &L.part, &L.st, &L.uni};
-      for (uint32_t* po : offs) *po += extra;
-      uint32_t new_uni = uni;
-      if (L.uni + new_uni > budget) new_uni = std::max(min_uni, budget > L.uni ? (budget - L.uni) & ~15u : min_uni);
-      o = L.uni + new_uni;
-      a->p.stage_cap = new_uni / 8;
-    }
-  }
-  (void)o_lookup;
   a->dense = dense ? 1u : 0u;
+  a->p.stage_cap = (lookup_bytes + uni) / 6;
   L.total = o;
   if (o > lds_limit)
     return fail(SGPU_ELIMIT,
@@ -459,7 +455,6 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   a->p.first_sorted = sp.first_sorted != 0;
   a->p.mode = mode == MODE_COUNTED ? (uint32_t)MODE_SEARCH : mode;
   a->p.use_bitmap = (mode == MODE_COUNTED || env_u32("SGPU_VISITED_BITMAP", 0)) ? 1u : 0u;
-  if (!dense) a->p.stage_cap = uni / 8;
   a->p.items_max = items_max;
   a->p.items_init = std::min<uint32_t>(items_max, env_u32("SGPU_ITEMS_INIT", 128));
   a->p.items_min = std::min<uint32_t>(a->p.items_init, env_u32("SGPU_ITEMS_MIN", 64));

@@ -15,12 +15,12 @@ struct DevView {
   const uint64_t* post_ref;           // n_postings: (record offset / 16) << 16 | len
                                       //   (the reference's PackedPostingBlock, src/posting_list.rs:32-60)
   const uint32_t* post_doc;           // n_postings: document id (visited set key, result id)
-  const float2* blk_mq;               // n_blocks: (minimum, quant) of the block's summary
   const uint32_t* list_row_start;     // dim + 1
   const void* row_comp;               // n_rows, ascending within a list
   const uint32_t* row_ptr;            // n_rows + 1
   const uint16_t* sum_bid;            // n_entries: list-local block id
-  const uint8_t* sum_code;            // n_entries: u8 code
+  const float* sum_deq;               // n_entries: code*quant + min of the entry's block, rounded as the
+                                      //   reference does (src/quantized_summary.rs:102-104), precomputed at upload
   uint32_t dim, n_docs, n_bitmap_words;
 };
 

@@ -131,6 +131,7 @@ struct Lds {
   uint32_t* rt_pre;     // [QC*(QN+1)] flattened prefix of matched row lengths
   float* dots;
   uint16_t* order;
+  uint8_t* stage;       // stage-1 staging: from the lookup table region to the end of the union region
   uint8_t* uni;         // union region
   uint32_t* part;       // scan partials [NT/64 + 1]
   uint32_t* st;         // state words
@@ -153,6 +154,7 @@ SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
   l.rt_pre = (uint32_t*)(smem + L.rt_pre);
   l.dots = (float*)(smem + L.dots);
   l.order = (uint16_t*)(smem + L.order);
+  l.stage = smem + L.q_bits;
   l.uni = smem + L.uni;
   l.part = (uint32_t*)(smem + L.part);
   l.st = (uint32_t*)(smem + L.st);
@@ -162,31 +164,37 @@ SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
 // ---------------------------------------------------------------------------
 // stage 0: query into LDS, choose the lists
 // ---------------------------------------------------------------------------
-template <int NT, bool DENSE>
+template <int NT>
 SGPU_DEV void load_query(const Lds& s, const BatchView& qb, uint32_t q, uint32_t* nnz_out) {
   const uint32_t o0 = qb.q_off[q], o1 = qb.q_off[q + 1];
   const uint32_t nnz = o1 - o0;
   for (uint32_t j = threadIdx.x; j < nnz; j += NT) {
-    const uint32_t c = qb.q_comp[o0 + j];
-    s.q_comp[j] = c;
+    s.q_comp[j] = qb.q_comp[o0 + j];
     s.q_val[j] = qb.q_val[o0 + j];
-    if (DENSE) {
-      s.q_idx[c] = (uint8_t)(j + 1);
-    } else {
-      atomicOr(&s.q_word[c >> 5].x, 1u << (c & 31));
-      // rank of the first query component of each vocabulary word
-      if (j == 0 || (qb.q_comp[o0 + j - 1] >> 5) != (c >> 5)) s.q_word[c >> 5].y = j;
-    }
   }
   *nnz_out = nnz;
 }
 
+// (Re)builds the query lookup table used by the scoring loop. Its LDS region doubles as stage-1
+// staging, so it is cleared and filled between stage 1 and stage 2.
+//   dense : one byte per vocabulary id: 1 + rank of the id in the query, 0 = absent
+//   bitmap: {32 vocabulary bits, rank of the word's first query component} per 32 ids
 template <int NT, bool DENSE>
-SGPU_DEV void clear_query_bits(const Lds& s, uint32_t nnz) {
+SGPU_DEV void build_lookup(const Lds& s, uint32_t dim, uint32_t nnz) {
+  uint32_t* z = (uint32_t*)s.stage;
+  const uint32_t nz = DENSE ? (dim + 1 + 3) / 4 : 2 * ((dim + 31) / 32);
+  for (uint32_t i = threadIdx.x; i < nz; i += NT) z[i] = 0;
+  __syncthreads();
   for (uint32_t j = threadIdx.x; j < nnz; j += NT) {
-    if (DENSE) s.q_idx[s.q_comp[j]] = 0;
-    else s.q_word[s.q_comp[j] >> 5].x = 0;
+    const uint32_t c = s.q_comp[j];
+    if (DENSE) {
+      s.q_idx[c] = (uint8_t)(j + 1);
+    } else {
+      atomicOr(&s.q_word[c >> 5].x, 1u << (c & 31));
+      if (j == 0 || (s.q_comp[j - 1] >> 5) != (c >> 5)) s.q_word[c >> 5].y = j;
+    }
   }
+  __syncthreads();
 }
 
 // k_largest_by(query_cut, total_cmp) in descending order; ties: ascending component.
@@ -269,10 +277,14 @@ SGPU_DEV void build_row_table(const Lds& s, const DevView& ix, uint32_t nnz, uin
   __syncthreads();
 }
 
-// Computes dots for lists [0, nl). stage_cap = staging entries (8 bytes each) in the union region.
-// (a) copy: the whole workgroup streams the matched rows' (block id, code) entries from HBM,
-//     dequantises and multiplies ((code*quant + min) * qv -- the reference's roundings, no FMA)
-//     and parks (block id, product) in LDS. Entries are independent: full memory parallelism.
+// Computes dots for lists [0, nl). stage_cap = staging entries (6 bytes each) available from the
+// start of the lookup-table region to the end of the union region (the lookup table is only
+// needed in stage 2 and is rebuilt after this stage).
+// (a) copy: the whole workgroup streams the matched rows' (block id, dequantised value) entries
+//     from HBM with 8 independent entries in flight per thread, multiplies by the query weight and
+//     parks (block id, product) in LDS. The value array holds code*quant + min computed once at
+//     upload with the reference's roundings (src/quantized_summary.rs:102-104); the product
+//     `* qv` and the accumulation below follow :107-108. No FMA anywhere.
 // (b) accumulate: one wavefront per list adds the products row by row, in ascending query
 //     component order, to the list's accumulators (LDS only, in-order DS pipeline).
 template <int NT>
@@ -280,12 +292,13 @@ SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32
                            uint32_t stage_cap) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr uint32_t NW = NT / 64;
+  constexpr int SU = 8;
   const uint32_t total_blocks = s.sel_doff[nl];
   for (uint32_t i = threadIdx.x; i < total_blocks; i += NT) s.dots[i] = 0.0f;
-  uint2* stage = (uint2*)s.uni;
-  uint32_t cap_shift = 6;                           // staging window per list: a power of two >= 64
-  while ((2u << cap_shift) * nl <= stage_cap) ++cap_shift;
-  const uint32_t cap_l = 1u << cap_shift;
+  const uint32_t cap_l = (stage_cap / nl) & ~63u;   // staging window per list
+  const uint32_t inv_cap = 0xffffffffu / cap_l;
+  float* st_prod = (float*)s.stage;
+  uint16_t* st_bid = (uint16_t*)(st_prod + (size_t)cap_l * nl);
   uint32_t emax = 0;
   for (uint32_t l = 0; l < nl; ++l) {
     const uint32_t e = s.rt_pre[l * (qn + 1) + nnz];
@@ -293,18 +306,21 @@ SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32
   }
   __syncthreads();
   for (uint32_t w0 = 0; w0 < emax; w0 += cap_l) {
-    // thread per entry over the flattened (list, position) window, 4 independent entries in
-    // flight per thread: row lookup by binary search in LDS, then HBM loads back to back.
-    const uint32_t span = nl << cap_shift;
-    for (uint32_t base = threadIdx.x; base < span; base += 4 * NT) {
-      uint32_t sidx[4], g[4], lb0[4];
-      float qv[4];
-      bool ok[4];
+    const uint32_t span = nl * cap_l;
+    for (uint32_t base = threadIdx.x; base < span; base += SU * NT) {
+      uint32_t g[SU];
+      float qv[SU];
+      bool ok[SU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SU; ++u) {
         const uint32_t idx = base + (uint32_t)u * NT;
-        const uint32_t l = idx >> cap_shift;
-        const uint32_t f = w0 + (idx & (cap_l - 1));
+        uint32_t l = __umulhi(idx, inv_cap);
+        uint32_t r = idx - l * cap_l;
+        if (r >= cap_l) {
+          r -= cap_l;
+          ++l;
+        }
+        const uint32_t f = w0 + r;
         ok[u] = idx < span;
         const uint32_t* pre = s.rt_pre + (ok[u] ? l : 0u) * (qn + 1);
         ok[u] = ok[u] && f < pre[nnz];
@@ -313,33 +329,30 @@ SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32
           const uint32_t mid = (lo + hi) >> 1;
           if (pre[mid] <= f) lo = mid; else hi = mid;
         }
-        sidx[u] = idx;
-        g[u] = ok[u] ? s.rt_start[l * qn + lo] + (f - pre[lo]) : 0u;
+        g[u] = ok[u] ? s.rt_start[(ok[u] ? l : 0u) * qn + lo] + (f - pre[lo]) : 0u;
         qv[u] = s.q_val[lo];
-        lb0[u] = ok[u] ? s.sel_b0[l] : 0u;
       }
-      uint32_t bid[4];
-      float code[4];
+      uint32_t bid[SU];
+      float deq[SU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SU; ++u) {
         bid[u] = ok[u] ? (uint32_t)ix.sum_bid[g[u]] : 0u;
-        code[u] = ok[u] ? (float)ix.sum_code[g[u]] : 0.0f;
+        deq[u] = ok[u] ? ix.sum_deq[g[u]] : 0.0f;
       }
-      float2 m[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) m[u] = ok[u] ? ix.blk_mq[lb0[u] + bid[u]] : make_float2(0.f, 0.f);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < SU; ++u) {
         if (ok[u]) {
-          const float prod = __fmul_rn(__fadd_rn(__fmul_rn(code[u], m[u].y), m[u].x), qv[u]);
-          stage[sidx[u]] = make_uint2(bid[u], __float_as_uint(prod));
+          const uint32_t idx = base + (uint32_t)u * NT;
+          st_prod[idx] = __fmul_rn(deq[u], qv[u]);
+          st_bid[idx] = (uint16_t)bid[u];
         }
       }
     }
     __syncthreads();
     for (uint32_t l = wave; l < nl; l += NW) {
       float* acc = s.dots + s.sel_doff[l];
-      const uint2* src = stage + l * cap_l;
+      const float* sp = st_prod + l * cap_l;
+      const uint16_t* sb = st_bid + l * cap_l;
       const uint32_t* pre = s.rt_pre + l * (qn + 1);
       for (uint32_t j = 0; j < nnz; ++j) {
         const uint32_t p0 = pre[j], p1 = pre[j + 1];
@@ -348,8 +361,8 @@ SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32
         // block ids are distinct within a row, so lanes never collide; rows are applied
         // in order and a wavefront's DS operations execute in issue order.
         for (uint32_t f = a + lane; f < b; f += 64) {
-          const uint2 e = src[f - w0];
-          acc[e.x] = __fadd_rn(acc[e.x], __uint_as_float(e.y));
+          const uint32_t bid = sb[f - w0];
+          acc[bid] = __fadd_rn(acc[bid], sp[f - w0]);
         }
       }
     }
@@ -705,11 +718,6 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
   WorkCount wc;       // lane-local partial counts, wavefront 0
 
   // one-time LDS init
-  {
-    uint32_t* z = (uint32_t*)(smem + L.q_bits);
-    const uint32_t nz = DENSE ? (ix.dim + 1 + 3) / 4 : 2 * ((ix.dim + 31) / 32);
-    for (uint32_t i = threadIdx.x; i < nz; i += NT) z[i] = 0;
-  }
   if (threadIdx.x == 0) s.q_val[-1] = 0.0f;   // the weight every non-matching component resolves to
   __syncthreads();
 
@@ -736,7 +744,7 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
   }
     // ---- stage 0 ----
     uint32_t nnz;
-    load_query<NT, DENSE>(s, qb, q, &nnz);
+    load_query<NT>(s, qb, q, &nnz);
     heap.reset();
     wc = WorkCount{0, 0, 0, 0};
     uint32_t spec_docs = 0, st_entries = 0, st_rows = 0;
@@ -780,12 +788,11 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
         for (uint32_t i = threadIdx.x; i < s.sel_nb[0]; i += NT) qb.out_scores[i] = s.dots[i];
         if (threadIdx.x == 0) qb.out_n[q] = s.sel_nb[0];
         __syncthreads();
-        clear_query_bits<NT, DENSE>(s, nnz);
-        __syncthreads();
         continue;
       }
 
       // ---- stage 2 ----
+      build_lookup<NT, DENSE>(s, ix.dim, nnz);
       uint32_t budget = p.items_init;
       for (uint32_t l = 0; l < nl; ++l) {
         const uint32_t nb = s.sel_nb[l];
@@ -1016,7 +1023,6 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
     // ---- per-query cleanup: visited bitmap, query bits ----
     if (p.use_bitmap)
       for (uint32_t i = threadIdx.x; i < ix.n_bitmap_words; i += NT) bitmap[i] = 0;
-    clear_query_bits<NT, DENSE>(s, nnz);
     __threadfence_block();
     __syncthreads();
     TICK(11);
