@@ -307,29 +307,33 @@ SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32
   __syncthreads();
   for (uint32_t w0 = 0; w0 < emax; w0 += cap_l) {
     const uint32_t span = nl * cap_l;
-    for (uint32_t base = threadIdx.x; base < span; base += SU * NT) {
+    // every thread takes SU consecutive positions of one list's window: one row lookup (binary
+    // search in LDS) for the first, a short forward walk for the rest, then SU independent HBM loads
+    for (uint32_t base = threadIdx.x * SU; base < span; base += SU * NT) {
+      uint32_t l = __umulhi(base, inv_cap);
+      uint32_t r = base - l * cap_l;
+      if (r >= cap_l) {
+        r -= cap_l;
+        ++l;
+      }
+      const uint32_t* pre = s.rt_pre + l * (qn + 1);
+      const uint32_t* rts = s.rt_start + l * qn;
+      const uint32_t e_l = pre[nnz];
+      const uint32_t f0 = w0 + r;
+      uint32_t lo = 0, hi = nnz;   // last row j with pre[j] <= f0
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pre[mid] <= f0) lo = mid; else hi = mid;
+      }
       uint32_t g[SU];
       float qv[SU];
       bool ok[SU];
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
-        const uint32_t idx = base + (uint32_t)u * NT;
-        uint32_t l = __umulhi(idx, inv_cap);
-        uint32_t r = idx - l * cap_l;
-        if (r >= cap_l) {
-          r -= cap_l;
-          ++l;
-        }
-        const uint32_t f = w0 + r;
-        ok[u] = idx < span;
-        const uint32_t* pre = s.rt_pre + (ok[u] ? l : 0u) * (qn + 1);
-        ok[u] = ok[u] && f < pre[nnz];
-        uint32_t lo = 0, hi = nnz;   // last row j with pre[j] <= f
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (pre[mid] <= f) lo = mid; else hi = mid;
-        }
-        g[u] = ok[u] ? s.rt_start[(ok[u] ? l : 0u) * qn + lo] + (f - pre[lo]) : 0u;
+        const uint32_t f = f0 + (uint32_t)u;
+        ok[u] = f < e_l;
+        while (lo + 1 < nnz && pre[lo + 1] <= f) ++lo;
+        g[u] = ok[u] ? rts[lo] + (f - pre[lo]) : 0u;
         qv[u] = s.q_val[lo];
       }
       uint32_t bid[SU];
@@ -342,9 +346,8 @@ SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
         if (ok[u]) {
-          const uint32_t idx = base + (uint32_t)u * NT;
-          st_prod[idx] = __fmul_rn(deq[u], qv[u]);
-          st_bid[idx] = (uint16_t)bid[u];
+          st_prod[base + (uint32_t)u] = __fmul_rn(deq[u], qv[u]);
+          st_bid[base + (uint32_t)u] = (uint16_t)bid[u];
         }
       }
     }
@@ -618,6 +621,18 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_it
   while (i < n_items) {
     const uint32_t idx = i + lane;
     const bool valid = idx < n_items;
+    if (!USE_BITMAP && heap.len == k) {
+      // Fast skip: the k-th best score only rises, so a window in which no score exceeds it
+      // cannot change the heap; without a visited set to maintain there is nothing else to do.
+      // (Work counters are exact only in the counted pass, which never takes this shortcut.)
+      const float sc0 = valid ? __uint_as_float(it_words[2 * idx + 1]) : 0.0f;
+      const float bd0 = valid ? cb.it_dot[idx] : 0.0f;
+      if (__ballot(valid && sc0 > heap.thr) == 0ull) {
+        live_items += (uint32_t)__popcll(__ballot(valid && !(bd0 < __fmul_rn(heap_factor, heap.thr))));
+        i += 64;
+        continue;
+      }
+    }
     float sc = 0.0f;
     uint32_t doc = 0, blk = 0, len = 0;
     float bdot = 0.0f;
@@ -888,6 +903,7 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             }
             piece_items = n_items;
             // (c) phase A: posting refs + visited bits (thread per item)
+            if (threadIdx.x == 0) s.st[ST_TMP2] = 0;   // phase B's item counter
             for (uint32_t i = threadIdx.x; i < n_items; i += NT) {
               const uint32_t gi = i + item0;
               uint32_t lo = 0, hi = nblk;   // first block with cb_incl > gi
@@ -908,21 +924,25 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             }
             __syncthreads();
             TICK(6);
-            // (d) phase B: speculative scoring, 16 lanes per document, DU documents in flight per group
+            // (d) phase B: speculative scoring, 16 lanes per document. Groups pull documents two at a
+            // time from a shared counter (documents differ 25x in length), and fetch the first TWO
+            // 128-element slices of each document up front (a third of the documents need the second).
             {
-              const uint32_t grp = threadIdx.x >> 4, sub = threadIdx.x & 15;
-              constexpr uint32_t G = NT / 16;
-              constexpr int DU = SGPU_DU;
+              const uint32_t sub = threadIdx.x & 15;
               float* it_score = (float*)cb.it_ref;
               const uint32_t e0 = sub * 8u;
-              for (uint32_t i = grp; i < n_items; i += DU * G) {
-                uint32_t len[DU];
-                const uint8_t* rec[DU];
-                const uint8_t* val[DU];
-                DocChunk<CT> d[DU];
+              for (;;) {
+                uint32_t i = 0;
+                if (sub == 0) i = atomicAdd(&s.st[ST_TMP2], 2u);
+                i = __shfl(i, 0, 16);
+                if (i >= n_items) break;
+                uint32_t len[2];
+                const uint8_t* rec[2];
+                const uint8_t* val[2];
+                DocChunk<CT> d[2][2];
 #pragma unroll
-                for (int u = 0; u < DU; ++u) {
-                  const uint32_t iu = i + (uint32_t)u * G;
+                for (int u = 0; u < 2; ++u) {
+                  const uint32_t iu = i + (uint32_t)u;
                   const bool has = iu < n_items;
                   const uint64_t ref = has ? cb.it_ref[iu] : 0ull;
                   const bool run = has && (cb.it_doc[has ? iu : 0] >> 31) == 0;
@@ -931,20 +951,25 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
                   val[u] = rec[u] + (size_t)((len[u] + 7u) & ~7u) * sizeof(CT);
                 }
 #pragma unroll
-                for (int u = 0; u < DU; ++u) {
-                  d[u].c0 = d[u].c1 = d[u].v = make_uint4(0, 0, 0, 0);
-                  if (e0 < len[u]) load_chunk<CT>(d[u], rec[u], val[u], e0);
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                  for (int h = 0; h < 2; ++h) {
+                    d[u][h].c0 = d[u][h].c1 = d[u][h].v = make_uint4(0, 0, 0, 0);
+                    if (e0 + 128u * h < len[u]) load_chunk<CT>(d[u][h], rec[u], val[u], e0 + 128u * h);
+                  }
                 }
 #pragma unroll
-                for (int u = 0; u < DU; ++u) {
+                for (int u = 0; u < 2; ++u) {
                   float a = 0.0f;
-                  if (e0 < len[u]) a = accumulate_chunk<CT, DENSE>(s, d[u], e0, len[u], a);
-                  for (uint32_t e = e0 + 128u; e < len[u]; e += 128u) {   // documents longer than 128
-                    load_chunk<CT>(d[u], rec[u], val[u], e);
-                    a = accumulate_chunk<CT, DENSE>(s, d[u], e, len[u], a);
+#pragma unroll
+                  for (int h = 0; h < 2; ++h)
+                    if (e0 + 128u * h < len[u]) a = accumulate_chunk<CT, DENSE>(s, d[u][h], e0 + 128u * h, len[u], a);
+                  for (uint32_t e = e0 + 256u; e < len[u]; e += 128u) {   // documents longer than 256
+                    load_chunk<CT>(d[u][0], rec[u], val[u], e);
+                    a = accumulate_chunk<CT, DENSE>(s, d[u][0], e, len[u], a);
                   }
                   a = reduce16(a);
-                  const uint32_t iu = i + (uint32_t)u * G;
+                  const uint32_t iu = i + (uint32_t)u;
                   spec_docs += (sub == 0 && len[u] != 0);
                   if (sub == 0 && iu < n_items) it_score[2 * iu + 1] = a;
                 }
