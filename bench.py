@@ -163,6 +163,19 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     qps = total_q * args.steps / elapsed
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # roofline.traffic: HBM bytes per launch from a SEPARATE rocprofv3 --pmc pass (counters cannot be
+    # collected from inside this process); taken from --traffic-bytes or profiles/pmc_traffic.json
+    # when that measurement was made on this very workload, else null.
+    traffic_bytes = args.traffic_bytes
+    if traffic_bytes is None:
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = "docs=%d dim=%d queries=%d k=%d query_cut=%d heap_factor=%s first_sorted=%d" % (
+                args.docs, args.dim, args.queries, args.k, args.query_cut, args.heap_factor, args.first_sorted)
+            if pm.get("workload") == key:
+                traffic_bytes = float(pm["traffic_bytes"])
+        except (OSError, ValueError, KeyError):
+            pass
     out = {
         "metric": "queries/sec at fixed recall@10 vs exact (Seismic search hot path, SPLADE-shape synthetic)",
         "value": qps,
@@ -197,7 +210,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": args.traffic_bytes,
+            "traffic": traffic_bytes,
             "kernel": "seismic_search_kernel",
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": algo_bytes,
