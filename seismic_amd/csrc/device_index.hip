@@ -408,7 +408,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   L.dots = o; o += up16(dots_cap * 4);
   L.order = o; o += up16((sp.first_sorted && searching) ? sort_nb * 2 : 0);
   L.part = o; o += up16((NT / 64 + 1) * 4);
-  L.st = o; o += up16(8 * 4);
+  L.st = o; o += up16(136 * 4);   // state words + candidate lists (ST_WORDS)
   // [lookup table | union region]: stage 1 uses both as one staging area (the lookup table is
   // built after stage 1); stage 2 uses the lookup table + the union region (sort keys, item tables).
   const uint32_t chunk_bytes = items_max * 18 + NT * 12;

@@ -136,7 +136,9 @@ struct Lds {
   uint32_t* part;       // scan partials [NT/64 + 1]
   uint32_t* st;         // state words
 };
-enum { ST_Q = 0, ST_NLISTS = 1, ST_THR = 2, ST_HLEN = 3, ST_TMP0 = 4, ST_TMP1 = 5, ST_TMP2 = 6, ST_TMP3 = 7, ST_WORDS = 8 };
+enum { ST_Q = 0, ST_NLISTS = 1, ST_THR = 2, ST_HLEN = 3, ST_TMP0 = 4, ST_TMP1 = 5, ST_TMP2 = 6, ST_NCAND = 7,
+       ST_CAND = 8 /* 64 candidate item indices */, ST_CAND_SORTED = 72 /* 64 */, ST_WORDS = 136 };
+constexpr uint32_t kMaxCand = 64;
 
 SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
   Lds l;
@@ -717,6 +719,45 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_it
   }
 }
 
+// Replay when the heap was already full at the start of the round and no visited bitmap is kept:
+// only items whose score exceeds the round's starting threshold can change the heap (the
+// threshold never decreases). Phase B collected their indices (<= kMaxCand, unordered); they are
+// ranked by item index and walked in order with the same liveness / membership / push rules as
+// replay_chunk, everything in registers.
+template <int KR>
+SGPU_DEV void replay_candidates(RegHeap<KR>& heap, const ChunkBufs& cb, const uint32_t* st, uint32_t nc,
+                                uint32_t k, float heap_factor, uint32_t& decided_blk) {
+  const uint32_t lane = lane_id();
+  const uint32_t* it_words = (const uint32_t*)cb.it_ref;
+  uint32_t idx = lane < nc ? st[ST_CAND + lane] : 0xffffffffu;
+  uint32_t rank = 0;
+  for (uint32_t l = 0; l < nc; ++l) rank += readlane_u(idx, l) < idx;
+  uint32_t* sorted = (uint32_t*)st + ST_CAND_SORTED;
+  if (lane < nc) sorted[rank] = idx;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  idx = lane < nc ? sorted[lane] : 0u;
+  float sc = 0.0f, bdot = 0.0f;
+  uint32_t doc = 0, blk = 0;
+  if (lane < nc) {
+    sc = __uint_as_float(it_words[2 * idx + 1]);
+    bdot = cb.it_dot[idx];
+    doc = cb.it_doc[idx] & 0x7fffffffu;
+    blk = cb.it_blk[idx];
+  }
+  for (uint32_t c = 0; c < nc; ++c) {
+    const float sc_c = readlane_f(sc, c);
+    const float thr = heap.thr;
+    if (!(sc_c > thr)) continue;
+    const uint32_t blk_c = readlane_u(blk, c);
+    const bool live = (blk_c == decided_blk) || !(readlane_f(bdot, c) < __fmul_rn(heap_factor, thr));
+    if (!live) continue;
+    const uint32_t doc_c = readlane_u(doc, c);
+    if (heap_contains<KR>(heap, doc_c)) continue;   // re-encountered document: already in the heap
+    heap.insert(sc_c, doc_c, k);
+    decided_blk = blk_c;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
@@ -903,7 +944,10 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             }
             piece_items = n_items;
             // (c) phase A: posting refs + visited bits (thread per item)
-            if (threadIdx.x == 0) s.st[ST_TMP2] = 0;   // phase B's item counter
+            if (threadIdx.x == 0) {
+              s.st[ST_TMP2] = 0;    // phase B's item counter
+              s.st[ST_NCAND] = 0;   // phase B's candidate counter
+            }
             for (uint32_t i = threadIdx.x; i < n_items; i += NT) {
               const uint32_t gi = i + item0;
               uint32_t lo = 0, hi = nblk;   // first block with cb_incl > gi
@@ -931,6 +975,8 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
               const uint32_t sub = threadIdx.x & 15;
               float* it_score = (float*)cb.it_ref;
               const uint32_t e0 = sub * 8u;
+              const bool collect = !p.use_bitmap && s.st[ST_HLEN] == p.k;   // heap full: only scores above the
+              const float thr0 = __uint_as_float(s.st[ST_THR]);            // current k-th best can matter
               for (;;) {
                 uint32_t i = 0;
                 if (sub == 0) i = atomicAdd(&s.st[ST_TMP2], 2u);
@@ -971,7 +1017,13 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
                   a = reduce16(a);
                   const uint32_t iu = i + (uint32_t)u;
                   spec_docs += (sub == 0 && len[u] != 0);
-                  if (sub == 0 && iu < n_items) it_score[2 * iu + 1] = a;
+                  if (sub == 0 && iu < n_items) {
+                    it_score[2 * iu + 1] = a;
+                    if (collect && len[u] != 0 && a > thr0) {
+                      const uint32_t slot = atomicAdd(&s.st[ST_NCAND], 1u);
+                      if (slot < kMaxCand) s.st[ST_CAND + slot] = iu;
+                    }
+                  }
                 }
               }
             }
@@ -980,7 +1032,12 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             // (e) exact replay on wavefront 0
             if (wave == 0) {
               uint32_t live_items = 0;
-              if (p.use_bitmap)
+              const uint32_t nc = s.st[ST_NCAND];
+              if (!p.use_bitmap && heap.len == p.k && nc <= kMaxCand) {
+                // (the heap was full when the round started: phase B collected every item that can matter)
+                replay_candidates<KR>(heap, cb, s.st, nc, p.k, p.heap_factor, decided_blk);
+                live_items = n_items;
+              } else if (p.use_bitmap)
                 replay_chunk<KR, true>(heap, cb, n_items, p.k, p.heap_factor, bitmap, decided_blk, piece == 0, wc,
                                        live_items);
               else
