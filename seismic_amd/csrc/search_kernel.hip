@@ -1,48 +1,56 @@
 // search_kernel.hip — the Seismic search hot path as one persistent gfx950 kernel.
 //
 // One query per workgroup (persistent workgroups pull queries from an atomic
-// queue). Per query, following InvertedIndexBase::search (reference
-// src/inverted_index.rs:153-234):
+// queue, longest-expected first). Per query, following InvertedIndexBase::search
+// (reference src/inverted_index.rs:153-234):
 //
-//   stage 0  query -> LDS: sorted (component, value) pairs, a vocabulary bitmap
-//            and per-word rank so a document component is tested with one
-//            ds_read and resolved to its query weight in O(1);
-//            the query_cut heaviest components are ranked (k_largest_by,
-//            src/inverted_index.rs:187-190) -> the posting lists to walk.
+//   stage 0  query -> LDS: sorted (component, value) pairs; the query_cut heaviest
+//            components are ranked (k_largest_by, src/inverted_index.rs:187-190)
+//            -> the posting lists to walk, in order.
 //   stage 1  hot loop A, QuantizedSummary::distances (src/quantized_summary.rs:64-160)
-//            for ALL selected lists at once (it is a pure function of the
-//            query): matching summary rows are located by binary search,
-//            their (block id, u8 code) entries are streamed HBM -> LDS by the
-//            whole workgroup, and one wavefront per list applies them row by
-//            row to f32 accumulators in LDS. A wavefront issues its DS
-//            operations in order and block ids are distinct within a row, so
-//            every accumulator receives its additions in ascending query
-//            component order with the reference's roundings
-//            ((code*quant + min) * qv, then +=; no FMA): BIT-EXACT dots.
+//            for ALL selected lists at once (a pure function of the query):
+//            matching summary rows are located by binary search; their (block id,
+//            dequantised value) entries are streamed HBM -> LDS by the whole
+//            workgroup (8 independent loads in flight per thread), multiplied by
+//            the query weight on the way; then one wavefront per list adds the
+//            products row by row to f32 accumulators in LDS. A wavefront issues its
+//            DS operations in order and block ids are distinct within a row, so
+//            every accumulator receives its additions in ascending query component
+//            order with the reference's roundings ((code*quant + min) * qv, then
+//            +=; no FMA; code*quant + min is precomputed once at upload): BIT-EXACT.
+//   lookup   between the stages the query lookup table is built in the LDS region
+//            stage 1 used for staging: one byte per vocabulary id (1 + rank in the
+//            query, 0 = absent) when it fits, else {32 bits, rank} per 32 ids.
 //   stage 2  hot loop B, PostingList::search / sort_and_search /
 //            evaluate_posting_block (src/posting_list.rs:115-215), list by list.
-//            The reference's skip test reads the LIVE k-th best score, so the
-//            set of scored documents depends on the traversal order. The
-//            threshold only ever rises, hence testing a block against an OLDER
-//            threshold can only admit more blocks. Each round therefore
-//              (a) filters the remaining blocks against the current threshold
-//                  and compacts the survivors (in traversal order),
-//              (b) expands them to postings and scores every not-yet-visited
-//                  document SPECULATIVELY: 16 lanes per document, 16-byte
-//                  loads of the doc record (components | f16 values),
-//              (c) REPLAYS the reference's sequential decisions on one
-//                  wavefront over the (block dot, doc score) table in LDS:
-//                  same skip tests with the live threshold, same heap pushes
-//                  in the same order, visited marks only for documents the
-//                  reference would have scored.
+//            The reference's skip test reads the LIVE k-th best score, so the set of
+//            scored documents depends on the traversal order. The threshold only
+//            rises, hence testing a block against an OLDER threshold can only admit
+//            more blocks. Each round therefore
+//              (a) filters the remaining blocks against the current threshold and
+//                  compacts the survivors in traversal order, under an item budget;
+//              (b) fetches their postings and scores every document SPECULATIVELY:
+//                  16 lanes per document, 16-byte loads of the record (components |
+//                  f16 values), two documents and two 128-element slices in flight
+//                  per lane group, documents pulled from a shared counter;
+//              (c) REPLAYS the reference's sequential decisions on one wavefront over
+//                  the (block dot, doc score) table in LDS: same skip tests with the
+//                  live threshold, same heap pushes in the same order. Once the heap
+//                  is full only items scoring above the round's starting threshold
+//                  can matter; phase (b) collects them and the replay walks just
+//                  those, in order, in registers.
 //            The result is the reference's exact candidate set and top-k.
-//   top-k    KHeap (src/utils.rs:12-66) lives in the VGPRs of wavefront 0 as a
-//            sorted array (entry e in lane e%64, register e/64): insertion is a
-//            ballot + one lane shift, the threshold is a readlane.
+//   visited  the reference's FxHashSet (src/inverted_index.rs:181-184) is replaced by
+//            an exactly equivalent heap-membership test at push time (proof at
+//            replay_chunk); a bitmap in HBM is kept only for the "counted" pass that
+//            reports exact work counters.
+//   top-k    KHeap (src/utils.rs:12-66) lives in the VGPRs of wavefront 0 as a sorted
+//            array (entry e in lane e%64, register e/64): insertion is a ballot + one
+//            DPP lane shift, the threshold is a readlane.
 //
-// No MFMA: this is gather / scatter-add / reduce work bounded by HBM latency
-// and bandwidth. Floating point follows the reference (Rust never contracts):
-// compiled with -ffp-contract=off and written with __fmul_rn/__fadd_rn.
+// No MFMA: this is gather / scatter-add / reduce work bounded by HBM latency and
+// bandwidth. Floating point follows the reference (Rust never contracts): compiled
+// with -ffp-contract=off and written with __fmul_rn/__fadd_rn.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
