@@ -587,10 +587,30 @@ SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0
   return acc;
 }
 
+// Sum over the 16 lanes of a group, valid in lane 0 of the group. DPP row rotations (no LDS
+// round trip): lane i adds lane (i + d) % 16 for d = 8, 4, 2, 1. For lane 0 every partner is the
+// same as in the butterfly t[j] += t[j ^ d] of the canonical order, so the value is bit-identical.
+SGPU_DEV float dpp_row_ror(float v, int ctrl8421) {
+  const int x = (int)__float_as_uint(v);
+  int r;
+  switch (ctrl8421) {
+    case 8: r = __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false); break;
+    case 4: r = __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, false); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x122, 0xf, 0xf, false); break;
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x121, 0xf, 0xf, false); break;
+  }
+  return __uint_as_float((uint32_t)r);
+}
 SGPU_DEV float reduce16(float acc) {
-#pragma unroll
-  for (int d = 8; d >= 1; d >>= 1) acc = __fadd_rn(acc, __shfl_xor(acc, d, 16));
+  acc = __fadd_rn(acc, dpp_row_ror(acc, 8));
+  acc = __fadd_rn(acc, dpp_row_ror(acc, 4));
+  acc = __fadd_rn(acc, dpp_row_ror(acc, 2));
+  acc = __fadd_rn(acc, dpp_row_ror(acc, 1));
   return acc;
+}
+// lane 0 of each 16-lane row, broadcast to the row (DPP row_share:0)
+SGPU_DEV uint32_t row_bcast0(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150, 0xf, 0xf, false);
 }
 
 // Work the reference algorithm performs for this query (lane-local partial counts, wave 0).
@@ -985,11 +1005,13 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
               const uint32_t e0 = sub * 8u;
               const bool collect = !p.use_bitmap && s.st[ST_HLEN] == p.k;   // heap full: only scores above the
               const float thr0 = __uint_as_float(s.st[ST_THR]);            // current k-th best can matter
+              uint32_t i_next = 0;
+              if (sub == 0) i_next = atomicAdd(&s.st[ST_TMP2], 2u);
               for (;;) {
-                uint32_t i = 0;
-                if (sub == 0) i = atomicAdd(&s.st[ST_TMP2], 2u);
-                i = __shfl(i, 0, 16);
+                const uint32_t i = row_bcast0(i_next);
                 if (i >= n_items) break;
+                // the pull for the following step is issued before this step's work
+                if (sub == 0) i_next = atomicAdd(&s.st[ST_TMP2], 2u);
                 uint32_t len[2];
                 const uint8_t* rec[2];
                 const uint8_t* val[2];
