@@ -427,9 +427,17 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   const bool dense_ok = d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255 &&
                         !env_u32("SGPU_NO_DENSE", 0) && searching;
   const bool dense = dense_ok && (o + dense_bytes + min_uni <= budget || env_u32("SGPU_FORCE_DENSE", 0));
-  const uint32_t lookup_bytes = mode == MODE_DOTS ? 0u : (dense ? dense_bytes : bitmap_bytes);
-  L.q_bits = o; o += lookup_bytes;
-  L.q_rank = o;
+  // large vocabularies: bits + 16-bit ranks (6 B per 32 ids) when the packed table (8 B) would
+  // cost the second workgroup per CU
+  const uint32_t split_bits = up16(words * 4), split_bytes = split_bits + up16(words * 2);
+  const bool split = !dense && d->comp_width == 4 && b->max_nnz <= 65535 &&
+                     (o + bitmap_bytes + min_uni > budget || env_u32("SGPU_FORCE_SPLIT", 0)) &&
+                     !env_u32("SGPU_NO_SPLIT", 0);
+  const uint32_t lookup = dense ? LK_DENSE : (split ? LK_SPLIT : LK_PACKED);
+  const uint32_t lookup_bytes = mode == MODE_DOTS ? 0u : (dense ? dense_bytes : (split ? split_bytes : bitmap_bytes));
+  L.q_bits = o;
+  L.q_rank = o + (split ? split_bits : lookup_bytes);
+  o += lookup_bytes;
   L.uni = o;
   uint32_t uni = min_uni;
   const uint32_t min_stage = qc * 64u * 6u + 16u;
@@ -440,7 +448,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   o += uni;
   L.qc = qc;
   L.qn = qn;
-  a->dense = dense ? 1u : 0u;
+  a->lookup = lookup;
   a->p.stage_cap = (lookup_bytes + uni) / 6;
   L.total = o;
   if (o > lds_limit)

@@ -38,6 +38,8 @@ struct BatchView {
 };
 
 enum { MODE_SEARCH = 0, MODE_DOTS = 1, MODE_COUNTED = 2 };   // COUNTED: search with the visited bitmap (exact counters)
+// query lookup table in LDS: {32 bits, rank} per 32 ids | one byte per id | bits + 16-bit ranks
+enum { LK_PACKED = 0, LK_DENSE = 1, LK_SPLIT = 2 };
 enum { STATS_WORDS = 24 };   // per-query stats: 8 work counters + 12 phase clocks (>>4) + slot + pad
 
 struct KParams {
@@ -68,7 +70,7 @@ struct LaunchArgs {
   uint32_t* queue;
   uint32_t* bitmaps;
   uint32_t comp_width, grid, block, lds_bytes;
-  uint32_t dense;   // 1: dense u8 query index in LDS (u16 components, dim <= 65535, query <= 255 components)
+  uint32_t lookup;  // LK_*: layout of the query lookup table in LDS
   hipStream_t stream;
 };
 

@@ -129,6 +129,8 @@ struct Lds {
   float* q_val;
   uint2* q_word;        // bitmap mode: [ceil(dim/32)] {32 vocabulary bits, rank of the word's first query component}
   uint8_t* q_idx;       // dense mode (same LDS region): [dim] 1 + rank of the component in the query, 0 = absent
+  uint32_t* q_bits32;   // split mode (same region): [ceil(dim/32)] bits, followed by
+  uint16_t* q_rank16;   //   [ceil(dim/32)] rank of the word's first query component
   uint32_t* sel_comp;   // [QC] list (component) ids in traversal order
   uint32_t* sel_nb;     // [QC] blocks in the list
   uint32_t* sel_b0;     // [QC] first global block id
@@ -154,6 +156,8 @@ SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
   l.q_val = (float*)(smem + L.q_val) + 1;   // q_val[-1] is the 0.0 every non-matching component resolves to
   l.q_word = (uint2*)(smem + L.q_bits);
   l.q_idx = smem + L.q_bits;
+  l.q_bits32 = (uint32_t*)(smem + L.q_bits);
+  l.q_rank16 = (uint16_t*)(smem + L.q_rank);
   l.sel_comp = (uint32_t*)(smem + L.sel);
   l.sel_nb = l.sel_comp + L.qc;
   l.sel_b0 = l.sel_nb + L.qc;
@@ -185,23 +189,28 @@ SGPU_DEV void load_query(const Lds& s, const BatchView& qb, uint32_t q, uint32_t
   *nnz_out = nnz;
 }
 
+// Query lookup table layouts (device_types.hpp: LK_*).
 // (Re)builds the query lookup table used by the scoring loop. Its LDS region doubles as stage-1
 // staging, so it is cleared and filled between stage 1 and stage 2.
 //   dense : one byte per vocabulary id: 1 + rank of the id in the query, 0 = absent
 //   bitmap: {32 vocabulary bits, rank of the word's first query component} per 32 ids
-template <int NT, bool DENSE>
+template <int NT, int LK>
 SGPU_DEV void build_lookup(const Lds& s, uint32_t dim, uint32_t nnz) {
   uint32_t* z = (uint32_t*)s.stage;
-  const uint32_t nz = DENSE ? (dim + 1 + 3) / 4 : 2 * ((dim + 31) / 32);
+  const uint32_t words = (dim + 31) / 32;
+  const uint32_t nz = LK == LK_DENSE ? (dim + 1 + 3) / 4 : (LK == LK_PACKED ? 2 * words : words);   // split: bits only
   for (uint32_t i = threadIdx.x; i < nz; i += NT) z[i] = 0;
   __syncthreads();
   for (uint32_t j = threadIdx.x; j < nnz; j += NT) {
     const uint32_t c = s.q_comp[j];
-    if (DENSE) {
+    if (LK == LK_DENSE) {
       s.q_idx[c] = (uint8_t)(j + 1);
-    } else {
+    } else if (LK == LK_PACKED) {
       atomicOr(&s.q_word[c >> 5].x, 1u << (c & 31));
       if (j == 0 || (s.q_comp[j - 1] >> 5) != (c >> 5)) s.q_word[c >> 5].y = j;
+    } else {   // split: 32 bits + a 16-bit rank per 32 ids (large vocabularies: 6 B instead of 8 B)
+      atomicOr(&s.q_bits32[c >> 5], 1u << (c & 31));
+      if (j == 0 || (s.q_comp[j - 1] >> 5) != (c >> 5)) s.q_rank16[c >> 5] = (uint16_t)j;
     }
   }
   __syncthreads();
@@ -545,7 +554,7 @@ SGPU_DEV void load_chunk(DocChunk<CT>& d, const uint8_t* rec, const uint8_t* val
   d.v = *(const uint4*)(vals + (size_t)e0 * 2);
 }
 
-template <typename CT, bool DENSE>
+template <typename CT, int LK>
 SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0, uint32_t len, float acc) {
   uint32_t c[8];
   if (sizeof(CT) == 2) {
@@ -557,7 +566,7 @@ SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0
   }
   const uint32_t v[4] = {d.v.x, d.v.y, d.v.z, d.v.w};
   float qv[8];
-  if (DENSE) {
+  if (LK == LK_DENSE) {
     // one byte per vocabulary id: 1 + rank in the query, 0 = absent (-> q_val[-1] == 0.0).
     // Padding components carry the sentinel id `dim`, whose byte is always 0: no length test.
     uint32_t r[8];
@@ -568,7 +577,10 @@ SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0
   } else {
     uint2 w[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = s.q_word[c[i] >> 5];
+    for (int i = 0; i < 8; ++i) {
+      if (LK == LK_PACKED) w[i] = s.q_word[c[i] >> 5];
+      else w[i] = make_uint2(s.q_bits32[c[i] >> 5], (uint32_t)s.q_rank16[c[i] >> 5]);
+    }
     int r[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -789,7 +801,7 @@ SGPU_DEV void replay_candidates(RegHeap<KR>& heap, const ChunkBufs& cb, const ui
 // ---------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------
-template <typename CT, int NT, int KR, bool DENSE>
+template <typename CT, int NT, int KR, int LK>
 __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(DevView ix, BatchView qb, KParams p,
                                                            LdsLayout L, uint32_t* queue,
                                                            uint32_t* bitmaps) {
@@ -876,7 +888,7 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
       }
 
       // ---- stage 2 ----
-      build_lookup<NT, DENSE>(s, ix.dim, nnz);
+      build_lookup<NT, LK>(s, ix.dim, nnz);
       uint32_t budget = p.items_init;
       for (uint32_t l = 0; l < nl; ++l) {
         const uint32_t nb = s.sel_nb[l];
@@ -1039,10 +1051,10 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
                   float a = 0.0f;
 #pragma unroll
                   for (int h = 0; h < 2; ++h)
-                    if (e0 + 128u * h < len[u]) a = accumulate_chunk<CT, DENSE>(s, d[u][h], e0 + 128u * h, len[u], a);
+                    if (e0 + 128u * h < len[u]) a = accumulate_chunk<CT, LK>(s, d[u][h], e0 + 128u * h, len[u], a);
                   for (uint32_t e = e0 + 256u; e < len[u]; e += 128u) {   // documents longer than 256
                     load_chunk<CT>(d[u][0], rec[u], val[u], e);
-                    a = accumulate_chunk<CT, DENSE>(s, d[u][0], e, len[u], a);
+                    a = accumulate_chunk<CT, LK>(s, d[u][0], e, len[u], a);
                   }
                   a = reduce16(a);
                   const uint32_t iu = i + (uint32_t)u;
@@ -1151,9 +1163,9 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
 // ---------------------------------------------------------------------------
 // host-callable launcher table
 // ---------------------------------------------------------------------------
-template <typename CT, int NT, int KR, bool DENSE>
+template <typename CT, int NT, int KR, int LK>
 static hipError_t run_one(const LaunchArgs& a, int* occupancy) {
-  auto kern = seismic_search_kernel<CT, NT, KR, DENSE>;
+  auto kern = seismic_search_kernel<CT, NT, KR, LK>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)a.lds_bytes);
   if (e != hipSuccess) return e;
@@ -1163,20 +1175,21 @@ static hipError_t run_one(const LaunchArgs& a, int* occupancy) {
   return hipGetLastError();
 }
 
-template <typename CT, int NT, bool DENSE>
+template <typename CT, int NT, int LK>
 static hipError_t run_kr(const LaunchArgs& a, int* occ) {
   const uint32_t k = a.p.k;
-  if (k <= 64) return run_one<CT, NT, 1, DENSE>(a, occ);
-  if (k <= 128) return run_one<CT, NT, 2, DENSE>(a, occ);
-  return run_one<CT, NT, 16, DENSE>(a, occ);
+  if (k <= 64) return run_one<CT, NT, 1, LK>(a, occ);
+  if (k <= 128) return run_one<CT, NT, 2, LK>(a, occ);
+  return run_one<CT, NT, 16, LK>(a, occ);
 }
 
 static hipError_t run_any(const LaunchArgs& a, int* occ) {
   if (a.comp_width == 2) {
-    if (a.dense) return a.block == 1024 ? run_kr<uint16_t, 1024, true>(a, occ) : run_kr<uint16_t, 512, true>(a, occ);
-    return a.block == 1024 ? run_kr<uint16_t, 1024, false>(a, occ) : run_kr<uint16_t, 512, false>(a, occ);
+    if (a.lookup == LK_DENSE) return a.block == 1024 ? run_kr<uint16_t, 1024, LK_DENSE>(a, occ) : run_kr<uint16_t, 512, LK_DENSE>(a, occ);
+    return a.block == 1024 ? run_kr<uint16_t, 1024, LK_PACKED>(a, occ) : run_kr<uint16_t, 512, LK_PACKED>(a, occ);
   }
-  return a.block == 1024 ? run_kr<uint32_t, 1024, false>(a, occ) : run_kr<uint32_t, 512, false>(a, occ);
+  if (a.lookup == LK_SPLIT) return a.block == 1024 ? run_kr<uint32_t, 1024, LK_SPLIT>(a, occ) : run_kr<uint32_t, 512, LK_SPLIT>(a, occ);
+  return a.block == 1024 ? run_kr<uint32_t, 1024, LK_PACKED>(a, occ) : run_kr<uint32_t, 512, LK_PACKED>(a, occ);
 }
 
 hipError_t occupancy_search(const LaunchArgs& a, int* n) { return run_any(a, n); }

@@ -61,6 +61,7 @@ def test_golden_synth_small_on_gpu():
 @pytest.mark.parametrize("env", [
     dict(SGPU_ITEMS_MAX="64", SGPU_ITEMS_INIT="16", SGPU_ITEMS_MIN="16", SGPU_RBLOCKS="1"),   # many rounds, oversize blocks
     dict(SGPU_NO_DENSE="1"),
+    dict(SGPU_FORCE_SPLIT="1"),
     dict(SGPU_BLOCK="1024", SGPU_STAGE_BYTES="8192"),                                        # many staging windows
     dict(SGPU_NO_LPT="1", SGPU_ITEMS_INIT="1024"),
     dict(SGPU_VISITED_BITMAP="1"),
@@ -81,7 +82,10 @@ def test_kernel_paths_under_forced_small_buffers(env, monkeypatch):
         _same(g, c)
 
 
-def test_large_vocabulary_u32_k100():
+@pytest.mark.parametrize("lookup_env", [dict(), dict(SGPU_FORCE_SPLIT="1")])
+def test_large_vocabulary_u32_k100(lookup_env, monkeypatch):
+    for k_, v_ in lookup_env.items():
+        monkeypatch.setenv(k_, v_)
     """BASELINE config 5 shape at test size: u32 components, 200K vocabulary, k=100, heap_factor sweep."""
     dim = 200_000
     docs = _native.synth(60_000, dim, 42, 0)
