@@ -38,7 +38,7 @@ extern "C" {
 typedef enum sgpu_status {
   SGPU_OK = 0,
   SGPU_EINVAL = 1,   /* bad argument: k==0, unsorted/duplicate query components,
-                        component >= dim, n_knn != 0, inconsistent descriptor */
+                        component >= dim, inconsistent descriptor */
   SGPU_EDEVICE = 2,  /* HIP failure / no device / index not uploaded */
   SGPU_ENOMEM = 3,   /* host or device allocation failed */
   SGPU_EIO = 4,      /* file could not be read / written / parsed */
@@ -113,7 +113,7 @@ typedef struct sgpu_search_params {
   uint32_t k;            /* > 0 */
   uint32_t query_cut;    /* number of heaviest query components whose lists are walked */
   float heap_factor;     /* skip block iff heap full && dot < heap_factor * kth_best */
-  uint32_t n_knn;        /* must be 0: no kNN graph on this path (src/inverted_index.rs:215) */
+  uint32_t n_knn;        /* neighbours of each result to rescore (Knn::refine); needs a graph, else ignored */
   int32_t first_sorted;  /* !=0: first list visited by descending summary dot
                             (PostingList::sort_and_search, src/posting_list.rs:149-185) */
 } sgpu_search_params;
@@ -159,6 +159,16 @@ sgpu_status sgpu_index_load(const char* path, sgpu_index** out);
 /* Copies the index into the HBM of HIP device `device` (one device per index;
  * multi-GPU = one process/index replica per GPU). */
 sgpu_status sgpu_index_upload(sgpu_index* idx, int32_t device);
+/* kNN graph — replaces Knn::new / Knn::refine (src/inverted_index.rs:448-500, 551-593).
+ * build: every document is searched as a query (k = nknn+1, query_cut 10, heap_factor 0.7) as
+ * batches through the GPU kernel; needs an uploaded index. set/get: attach or read the flattened
+ * neighbour lists (document d's neighbours at [d*knn_dim, (d+1)*knn_dim)). With a graph attached,
+ * sgpu_search_params.n_knn > 0 rescans the first n_knn neighbours of every top-k document after
+ * the posting lists; without one n_knn is ignored, as in the reference (src/inverted_index.rs:215-216). */
+sgpu_status sgpu_index_build_knn(sgpu_index* idx, uint32_t nknn);
+sgpu_status sgpu_index_set_knn(sgpu_index* idx, const uint32_t* neighbours, uint64_t n_total, uint32_t knn_dim);
+sgpu_status sgpu_index_get_knn(const sgpu_index* idx, const uint32_t** neighbours, uint64_t* n_total,
+                               uint32_t* knn_dim);
 /* Bytes resident in HBM after upload (0 before). */
 uint64_t sgpu_index_device_bytes(const sgpu_index* idx);
 void sgpu_index_destroy(sgpu_index* idx);

@@ -581,6 +581,13 @@ inline float score_doc(const sgpu_index_desc& ix, uint32_t doc, const float* den
   return t[0];
 }
 
+// Knn (reference src/inverted_index.rs:430-435): neighbour ids flattened in document order.
+struct KnnView {
+  const uint32_t* neighbours = nullptr;
+  uint64_t n_total = 0;
+  uint32_t dim = 0;
+};
+
 struct orc_stats_t {
   uint64_t algo_bytes;      // B_q of SURVEY.md section 8(d)
   uint64_t blocks_total;    // blocks of the walked lists
@@ -596,7 +603,8 @@ struct orc_stats_t {
 // (src/posting_list.rs:115-215).
 int search_one(const sgpu_index_desc& ix, QueryCtx& ctx, const uint32_t* qc, const float* qv,
                uint32_t nnz, uint32_t k, uint32_t query_cut, float heap_factor, int first_sorted,
-               int order, float* out_scores, uint64_t* out_ids, uint32_t* out_n, orc_stats_t* st) {
+               int order, float* out_scores, uint64_t* out_ids, uint32_t* out_n, orc_stats_t* st,
+               const KnnView* knn = nullptr, uint32_t in_n_knn = 0) {
   if (k == 0) return 1;                                      // KHeap::new assert (src/utils.rs:23)
   for (uint32_t i = 0; i < nnz; ++i) {
     if (qc[i] >= ix.dim) return 1;                           // Rust bounds panic (src/inverted_index.rs:193)
@@ -679,6 +687,24 @@ int search_one(const sgpu_index_desc& ix, QueryCtx& ctx, const uint32_t* qc, con
       }
     }
   }
+  // Knn::refine — reference src/inverted_index.rs:215-225, 551-593: snapshot of the heap (best
+  // first); for each of its documents the first n_knn neighbours; unvisited ones are scored + pushed.
+  if (in_n_knn > 0 && knn && knn->neighbours) {
+    const uint32_t n_knn = std::min(knn->dim, in_n_knn);
+    auto snap = heap.into_sorted_vec();
+    for (const auto& it : snap) {
+      const uint64_t base = (uint64_t)it.doc * knn->dim;
+      for (uint32_t i = 0; i < n_knn; ++i) {
+        if (base + i >= knn->n_total) break;   // the reference reads unchecked here (debug_assert only)
+        const uint32_t nb = knn->neighbours[base + i];
+        if (nb >= ix.n_docs) continue;
+        if (ctx.visited_epoch[nb] == ctx.epoch) continue;
+        ctx.visited_epoch[nb] = ctx.epoch;
+        heap.push({score_doc(ix, nb, ctx.dense.data(), order), nb});
+        if (st) st->docs_scored += 1;
+      }
+    }
+  }
   for (uint32_t i = 0; i < nnz; ++i) ctx.dense[qc[i]] = 0.0f;
   auto res = heap.into_sorted_vec();  // src/inverted_index.rs:227-233
   *out_n = (uint32_t)res.size();
@@ -713,6 +739,46 @@ orc_index* orc_index_build(uint32_t comp_width, uint64_t n_docs, uint64_t dim, c
 void orc_index_desc(orc_index* ix, sgpu_index_desc* out) { fill_desc((OracleIndex*)ix, out); }
 void orc_index_free(orc_index* ix) { delete (OracleIndex*)ix; }
 
+// kNN graph used by orc_search / orc_batch_search when params->n_knn > 0 (test infrastructure:
+// one process-wide attachment; pass NULL to detach).
+static KnnView g_knn;
+void orc_knn_attach(const uint32_t* neighbours, uint64_t n_total, uint32_t dim) {
+  g_knn.neighbours = neighbours;
+  g_knn.n_total = n_total;
+  g_knn.dim = dim;
+}
+
+// Knn::new — reference src/inverted_index.rs:448-500. out must hold n_docs * nknn ids; returns the
+// number written (documents with fewer than nknn results contribute fewer, as the reference's
+// flatten does).
+uint64_t orc_knn_build(const sgpu_index_desc* ix, uint32_t nknn, uint32_t* out) {
+  QueryCtx ctx;
+  const uint32_t k = nknn + 1;
+  std::vector<float> sc(k);
+  std::vector<uint64_t> ids(k);
+  std::vector<uint32_t> qc;
+  std::vector<float> qv;
+  uint64_t w = 0;
+  for (uint64_t d = 0; d < ix->n_docs; ++d) {
+    qc.clear();
+    qv.clear();
+    for (uint64_t i = ix->fwd_offsets[d]; i < ix->fwd_offsets[d + 1]; ++i) {
+      qc.push_back(comp_at(ix->fwd_comps, ix->comp_width, i));
+      qv.push_back(f16_to_f32(ix->fwd_vals[i]));
+    }
+    uint32_t n = 0;
+    search_one(*ix, ctx, qc.data(), qv.data(), (uint32_t)qc.size(), k, 10, 0.7f, 0, ORDER_LANES16, sc.data(),
+               ids.data(), &n, nullptr);
+    uint32_t taken = 0;
+    for (uint32_t i = 0; i < n && taken < nknn; ++i) {
+      if (ids[i] == d) continue;
+      out[w++] = (uint32_t)ids[i];
+      ++taken;
+    }
+  }
+  return w;
+}
+
 // hot loop A alone
 int orc_summary_distances(const sgpu_index_desc* ix, uint32_t list, const uint32_t* qc, const float* qv,
                           uint32_t nnz, float* out_dots, uint32_t* out_nb) {
@@ -728,10 +794,9 @@ int orc_summary_distances(const sgpu_index_desc* ix, uint32_t list, const uint32
 int orc_search(const sgpu_index_desc* ix, const uint32_t* qc, const float* qv, uint32_t nnz,
                const sgpu_search_params* p, int order, float* out_scores, uint64_t* out_ids,
                uint32_t* out_n, orc_stats_t* st) {
-  if (p->n_knn != 0) return 1;
   static thread_local QueryCtx ctx;
   return search_one(*ix, ctx, qc, qv, nnz, p->k, p->query_cut, p->heap_factor, p->first_sorted, order,
-                    out_scores, out_ids, out_n, st);
+                    out_scores, out_ids, out_n, st, &g_knn, p->n_knn);
 }
 
 // batch; num_threads 1 = the sequential loop of perf_inverted_index
@@ -741,7 +806,7 @@ int orc_batch_search(const sgpu_index_desc* ix, const uint64_t* q_off, const uin
                      const float* qv, uint32_t nq, const sgpu_search_params* p, int order,
                      uint32_t num_threads, float* out_scores, uint64_t* out_ids, uint32_t* out_n,
                      orc_stats_t* st_total, double* secs, uint32_t* threads_used) {
-  if (p->n_knn != 0 || p->k == 0) return 1;
+  if (p->k == 0) return 1;
   int nt = 1;
 #ifdef _OPENMP
   nt = num_threads ? (int)num_threads : omp_get_max_threads();
@@ -768,7 +833,7 @@ int orc_batch_search(const sgpu_index_desc* ix, const uint64_t* q_off, const uin
     int e = search_one(*ix, ctxs[(size_t)tid], qc + q_off[q], qv + q_off[q],
                        (uint32_t)(q_off[q + 1] - q_off[q]), p->k, p->query_cut, p->heap_factor,
                        p->first_sorted, order, out_scores + (size_t)q * p->k,
-                       out_ids + (size_t)q * p->k, out_n + q, &sts[(size_t)tid]);
+                       out_ids + (size_t)q * p->k, out_n + q, &sts[(size_t)tid], &g_knn, p->n_knn);
     if (e) {
 #pragma omp atomic write
       err = e;

@@ -48,6 +48,9 @@ def lib():
         L.sgpu_index_save.argtypes = [vp, C.c_char_p]
         L.sgpu_index_load.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.sgpu_index_upload.argtypes = [vp, C.c_int32]
+        L.sgpu_index_build_knn.argtypes = [vp, C.c_uint32]
+        L.sgpu_index_set_knn.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
+        L.sgpu_index_get_knn.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
         L.sgpu_search.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp,
                                   C.POINTER(C.c_uint32)]
         L.sgpu_batch_search.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp, vp]
@@ -138,6 +141,23 @@ class NativeIndex:
         check(lib().sgpu_index_upload(self.h, int(device)))
         return self
 
+    # ---- kNN graph (reference Knn, src/inverted_index.rs:430-594) ----
+    def build_knn(self, nknn):
+        """Knn::new on the GPU: every document searched as a query, batched through the kernel."""
+        check(lib().sgpu_index_build_knn(self.h, int(nknn)))
+
+    def set_knn(self, neighbours, knn_dim):
+        a = np.ascontiguousarray(neighbours, np.uint32)
+        check(lib().sgpu_index_set_knn(self.h, _p(a), len(a), int(knn_dim)))
+
+    def get_knn(self):
+        ptr, n, dim = C.c_void_p(), C.c_uint64(0), C.c_uint32(0)
+        check(lib().sgpu_index_get_knn(self.h, C.byref(ptr), C.byref(n), C.byref(dim)))
+        if n.value == 0:
+            return np.zeros(0, np.uint32), 0
+        arr = np.ctypeslib.as_array((C.c_uint32 * n.value).from_address(ptr.value)).copy()
+        return arr, int(dim.value)
+
     def device_bytes(self):
         return int(lib().sgpu_index_device_bytes(self.h))
 
@@ -207,15 +227,15 @@ class DeviceBatch:
         check(lib().sgpu_batch_create(index.h, _p(self.q_off), _p(self.comps), _p(self.vals), self.nq,
                                       self.k_max, C.byref(self.h)))
 
-    def run(self, k, query_cut, heap_factor, first_sorted=False, sync=True):
-        p = params(k, query_cut, heap_factor, first_sorted)
+    def run(self, k, query_cut, heap_factor, first_sorted=False, sync=True, n_knn=0):
+        p = params(k, query_cut, heap_factor, first_sorted, n_knn)
         st = LaunchStats()
         check(lib().sgpu_batch_run(self.index.h, self.h, C.byref(p), 1 if sync else 0, C.byref(st)))
         return st
 
-    def run_counted(self, k, query_cut, heap_factor, first_sorted=False):
+    def run_counted(self, k, query_cut, heap_factor, first_sorted=False, n_knn=0):
         """Synchronous pass with the visited bitmap: identical results, exact work counters."""
-        p = params(k, query_cut, heap_factor, first_sorted)
+        p = params(k, query_cut, heap_factor, first_sorted, n_knn)
         st = LaunchStats()
         check(lib().sgpu_batch_run_counted(self.index.h, self.h, C.byref(p), C.byref(st)))
         return st

@@ -22,6 +22,8 @@ sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out);
 sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list, const uint32_t* comps,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
 int device_count();
+sgpu_status device_index_set_knn(DeviceIndex* d, const std::vector<uint32_t>& knn, uint32_t knn_dim);
+sgpu_status build_knn_on_device(DeviceIndex* d, HostIndex& h, uint32_t nknn);
 }  // namespace sgpu
 
 using namespace sgpu;
@@ -100,6 +102,33 @@ sgpu_status sgpu_index_upload(sgpu_index* idx, int32_t device) {
     idx->dev = nullptr;
   }
   return device_index_upload(idx->host, device, &idx->dev);
+}
+
+sgpu_status sgpu_index_set_knn(sgpu_index* idx, const uint32_t* neighbours, uint64_t n_total, uint32_t knn_dim) {
+  if (!idx || (n_total && !neighbours)) return fail(SGPU_EINVAL, "null argument");
+  for (uint64_t i = 0; i < n_total; ++i)
+    if (neighbours[i] >= idx->host.n_docs) return fail(SGPU_EINVAL, "neighbour id >= n_docs");
+  try {
+    idx->host.knn.assign(neighbours, neighbours + n_total);
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of memory");
+  }
+  idx->host.knn_dim = n_total ? knn_dim : 0;
+  return device_index_set_knn(idx->dev, idx->host.knn, idx->host.knn_dim);
+}
+
+sgpu_status sgpu_index_get_knn(const sgpu_index* idx, const uint32_t** neighbours, uint64_t* n_total,
+                               uint32_t* knn_dim) {
+  if (!idx || !neighbours || !n_total || !knn_dim) return fail(SGPU_EINVAL, "null argument");
+  *neighbours = idx->host.knn.data();
+  *n_total = idx->host.knn.size();
+  *knn_dim = idx->host.knn_dim;
+  return SGPU_OK;
+}
+
+sgpu_status sgpu_index_build_knn(sgpu_index* idx, uint32_t nknn) {
+  if (!idx) return fail(SGPU_EINVAL, "null argument");
+  return build_knn_on_device(idx->dev, idx->host, nknn);
 }
 
 uint64_t sgpu_index_device_bytes(const sgpu_index* idx) { return idx ? device_index_bytes(idx->dev) : 0; }

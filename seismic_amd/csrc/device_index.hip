@@ -152,6 +152,12 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       pref[(size_t)p] = (rec_off16[doc] << 16) | len;
     }
     if ((st = dev_copy(d, pref.data(), pref.size(), &d->view.post_ref)) != SGPU_OK) return bail(st);
+    {
+      std::vector<uint64_t> dref(h.n_docs);
+      for (uint64_t doc = 0; doc < h.n_docs; ++doc)
+        dref[doc] = (rec_off16[doc] << 16) | (h.fwd_offsets[doc + 1] - h.fwd_offsets[doc]);
+      if ((st = dev_copy(d, dref.data(), dref.size(), &d->view.doc_ref)) != SGPU_OK) return bail(st);
+    }
     pref.clear();
     pref.shrink_to_fit();
     if ((st = dev_copy(d, h.post_doc.data(), h.post_doc.size(), &d->view.post_doc)) != SGPU_OK) return bail(st);
@@ -190,6 +196,14 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
           }
       }
       if ((st = dev_copy(d, deq.data(), deq.size(), &d->view.sum_deq)) != SGPU_OK) return bail(st);
+    }
+    d->view.knn = nullptr;
+    d->view.knn_total = 0;
+    d->view.knn_dim = 0;
+    if (!h.knn.empty() && h.knn_dim) {
+      if ((st = dev_copy(d, h.knn.data(), h.knn.size(), &d->view.knn)) != SGPU_OK) return bail(st);
+      d->view.knn_total = h.knn.size();
+      d->view.knn_dim = h.knn_dim;
     }
     d->view.dim = (uint32_t)h.dim;
     d->view.n_docs = (uint32_t)h.n_docs;
@@ -377,7 +391,6 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
                              LaunchArgs* a) {
   if (sp.k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
   if (sp.k > b->k_max) return fail(SGPU_EINVAL, "k = %u exceeds the batch's k_max = %u", sp.k, b->k_max);
-  if (sp.n_knn != 0) return fail(SGPU_EINVAL, "n_knn must be 0: no kNN graph on this path");
   if (std::isnan(sp.heap_factor)) return fail(SGPU_EINVAL, "heap_factor is NaN");
   const uint32_t NT = env_u32("SGPU_BLOCK", 512);
   if (NT != 512 && NT != 1024) return fail(SGPU_EINVAL, "SGPU_BLOCK must be 512 or 1024");
@@ -462,6 +475,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   a->p.heap_factor = sp.heap_factor;
   a->p.first_sorted = sp.first_sorted != 0;
   a->p.mode = mode == MODE_COUNTED ? (uint32_t)MODE_SEARCH : mode;
+  a->p.n_knn = mode == MODE_DOTS ? 0u : sp.n_knn;   // ignored when the index has no graph, as the reference does
   a->p.use_bitmap = (mode == MODE_COUNTED || env_u32("SGPU_VISITED_BITMAP", 0)) ? 1u : 0u;
   a->p.items_max = items_max;
   a->p.items_init = std::min<uint32_t>(items_max, env_u32("SGPU_ITEMS_INIT", 128));
@@ -627,6 +641,87 @@ sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list,
   }
   batch_free(b);
   return st;
+}
+
+
+// (Re)attaches a kNN graph to a resident index.
+sgpu_status device_index_set_knn(DeviceIndex* d, const std::vector<uint32_t>& knn, uint32_t knn_dim) {
+  if (!d) return SGPU_OK;
+  std::lock_guard<std::mutex> lock(d->mu);
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(d->stream));
+  d->view.knn = nullptr;
+  d->view.knn_total = 0;
+  d->view.knn_dim = 0;
+  if (knn.empty() || !knn_dim) return SGPU_OK;
+  sgpu_status st = dev_copy(d, knn.data(), knn.size(), &d->view.knn);
+  if (st != SGPU_OK) return st;
+  d->view.knn_total = knn.size();
+  d->view.knn_dim = knn_dim;
+  return SGPU_OK;
+}
+
+// Knn::new (reference src/inverted_index.rs:448-500): every document is used as a query with
+// k = nknn + 1, query_cut = 10, heap_factor = 0.7, first_sorted = false; itself is removed, the
+// first nknn remaining results are its neighbours; lists are flattened in document order (a
+// document with fewer results contributes fewer ids, exactly as the reference's flatten does).
+// The N_docs searches run as batches through the same GPU kernel.
+sgpu_status build_knn_on_device(DeviceIndex* d, HostIndex& h, uint32_t nknn) {
+  if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
+  if (nknn == 0 || nknn + 1 > 1024) return fail(SGPU_EINVAL, "nknn must be in 1..1023");
+  const uint32_t k = nknn + 1;
+  const uint64_t chunk = env_u32("SGPU_KNN_CHUNK", 32768);
+  std::vector<uint32_t> out;
+  out.reserve((size_t)h.n_docs * nknn);
+  sgpu_search_params sp{};
+  sp.k = k;
+  sp.query_cut = 10;
+  sp.heap_factor = 0.7f;
+  sp.n_knn = 0;
+  sp.first_sorted = 0;
+  // make sure no stale graph is used while building
+  sgpu_status st = device_index_set_knn(d, {}, 0);
+  if (st != SGPU_OK) return st;
+  std::vector<uint64_t> q_off;
+  std::vector<uint32_t> q_comp;
+  std::vector<float> q_val, sc;
+  std::vector<uint64_t> ids;
+  std::vector<uint32_t> n;
+  for (uint64_t d0 = 0; d0 < h.n_docs; d0 += chunk) {
+    const uint64_t d1 = std::min<uint64_t>(h.n_docs, d0 + chunk);
+    const uint32_t nq = (uint32_t)(d1 - d0);
+    const uint64_t e0 = h.fwd_offsets[d0], e1 = h.fwd_offsets[d1];
+    q_off.resize(nq + 1);
+    q_comp.resize(e1 - e0);
+    q_val.resize(e1 - e0);
+    for (uint32_t q = 0; q <= nq; ++q) q_off[q] = h.fwd_offsets[d0 + q] - e0;
+    for (uint64_t i = e0; i < e1; ++i) {
+      q_comp[i - e0] = h.comp(i);
+      q_val[i - e0] = f16_to_f32(h.fwd_vals[i]);
+    }
+    sgpu_batch* b = nullptr;
+    st = batch_create(d, h.dim, q_off.data(), q_comp.data(), q_val.data(), nq, k, &b);
+    if (st != SGPU_OK) return st;
+    st = batch_run(d, b, sp, MODE_SEARCH, 1, nullptr);
+    sc.resize((size_t)nq * k);
+    ids.resize((size_t)nq * k);
+    n.resize(nq);
+    if (st == SGPU_OK) st = batch_fetch(d, b, k, sc.data(), ids.data(), n.data());
+    batch_free(b);
+    if (st != SGPU_OK) return st;
+    for (uint32_t q = 0; q < nq; ++q) {
+      uint32_t taken = 0;
+      for (uint32_t i = 0; i < n[q] && taken < nknn; ++i) {
+        const uint64_t id = ids[(size_t)q * k + i];
+        if (id == d0 + q) continue;   // remove the document itself
+        out.push_back((uint32_t)id);
+        ++taken;
+      }
+    }
+  }
+  h.knn.swap(out);
+  h.knn_dim = nknn;
+  return device_index_set_knn(d, h.knn, h.knn_dim);
 }
 
 }  // namespace sgpu

@@ -21,6 +21,12 @@ struct DevView {
   const uint16_t* sum_bid;            // n_entries: list-local block id
   const float* sum_deq;               // n_entries: code*quant + min of the entry's block, rounded as the
                                       //   reference does (src/quantized_summary.rs:102-104), precomputed at upload
+  // kNN graph (reference: Knn, src/inverted_index.rs:430-594): flattened neighbour lists, and the
+  // record ref of every document (the refine step scores neighbours that come without a posting)
+  const uint32_t* knn;                // knn_total ids, document d's neighbours at [d*knn_dim, +knn_dim); null = no graph
+  const uint64_t* doc_ref;            // n_docs: same packing as post_ref
+  uint64_t knn_total;
+  uint32_t knn_dim;
   uint32_t dim, n_docs, n_bitmap_words;
 };
 
@@ -52,6 +58,7 @@ struct KParams {
   uint32_t items_init;   // first round's budget; adapts to the replay's keep ratio
   uint32_t items_min;    // lower bound of the budget
   uint32_t rblocks_max;  // blocks filtered per thread and round
+  uint32_t n_knn;        // neighbours of each result to rescore after the lists (Knn::refine); 0 = off
   uint32_t use_bitmap;   // 1: visited bitmap in HBM (exact work counters); 0: heap-membership dedup
   uint32_t target_list;  // MODE_DOTS: the posting list whose summary dots are wanted
 };

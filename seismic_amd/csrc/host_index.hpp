@@ -23,6 +23,10 @@ struct HostIndex {
   std::vector<uint64_t> row_ptr;
   std::vector<uint16_t> sum_bid;
   std::vector<uint8_t> sum_code;
+  // optional kNN graph (reference Knn, src/inverted_index.rs:430-435): neighbour ids flattened in
+  // document order, knn_dim per document (the reference flattens the same way, :487-493)
+  std::vector<uint32_t> knn;
+  uint32_t knn_dim = 0;
 
   uint64_t nnz() const { return fwd_offsets.empty() ? 0 : fwd_offsets.back(); }
   uint64_t n_blocks() const { return list_block_start.empty() ? 0 : list_block_start.back(); }

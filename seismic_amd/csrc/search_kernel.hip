@@ -656,7 +656,10 @@ SGPU_DEV bool heap_contains(const RegHeap<KR>& heap, uint32_t d) {
 template <int KR, bool USE_BITMAP>
 SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_items, uint32_t k,
                            float heap_factor, uint32_t* bitmap, uint32_t& decided_blk,
-                           bool block_starts_at_0, WorkCount& wc, uint32_t& live_items) {
+                           bool block_starts_at_0, WorkCount& wc, uint32_t& live_items, bool dups) {
+  // dups: the round may hold the same document more than once (kNN refinement: two results can
+  // share a neighbour; a posting list never repeats a document). The reference inserts into its
+  // visited set item by item, so a later copy must see the earlier one.
   const uint32_t lane = lane_id();
   const uint32_t* it_words = (const uint32_t*)cb.it_ref;   // [2i] = low ref word (len), [2i+1] = score
   uint32_t i = 0;
@@ -689,6 +692,10 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_it
       blk = cb.it_blk[idx];
       first = idx == 0 ? block_starts_at_0 : (cb.it_blk[idx - 1] != blk);
     }
+    if (dups && USE_BITMAP) {   // marks made earlier in this round (by this wavefront) must be seen
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+      if (valid && !vis) vis = visited_test(bitmap, doc);
+    }
     if (heap.len < k) {
       // heap not full: every block that starts now is evaluated, every new doc is pushed
       if (!USE_BITMAP) {   // visited == already in the heap
@@ -697,6 +704,11 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_it
           const uint32_t lim = heap.len > (uint32_t)r * 64u ? heap.len - (uint32_t)r * 64u : 0u;
           for (uint32_t l = 0; l < (lim < 64u ? lim : 64u); ++l) vis |= doc == readlane_u(heap.doc[r], l);
         }
+      }
+      if (dups) {   // a later copy of a document inside this window is "visited" by the earlier one
+        const uint64_t nv0 = __ballot(valid && !vis);
+        for (uint32_t l = 0; l < 63; ++l)
+          if (((nv0 >> l) & 1ull) && lane > l && doc == readlane_u(doc, l)) vis = true;
       }
       const uint64_t nvm = __ballot(valid && !vis);
       const uint32_t need = k - heap.len;
@@ -795,6 +807,97 @@ SGPU_DEV void replay_candidates(RegHeap<KR>& heap, const ChunkBufs& cb, const ui
     if (heap_contains<KR>(heap, doc_c)) continue;   // re-encountered document: already in the heap
     heap.insert(sc_c, doc_c, k);
     decided_blk = blk_c;
+  }
+}
+
+// Phase B: speculative scoring of the round's items, 16 lanes per document. Groups pull documents
+// two at a time from a shared counter (documents differ 25x in length) and fetch the first TWO
+// 128-element slices of each document up front (a third of the documents need the second).
+// When the heap is already full (and no visited bitmap is kept) the items scoring above the
+// round's starting threshold are collected for replay_candidates.
+template <typename CT, int NT, int LK>
+SGPU_DEV void score_items(const Lds& s, const DevView& ix, const ChunkBufs& cb, const KParams& p,
+                          uint32_t n_items, uint32_t& spec_docs) {
+  const uint32_t sub = threadIdx.x & 15;
+  float* it_score = (float*)cb.it_ref;
+  const uint32_t e0 = sub * 8u;
+  const bool collect = !p.use_bitmap && s.st[ST_HLEN] == p.k;   // heap full: only scores above the
+  const float thr0 = __uint_as_float(s.st[ST_THR]);            // current k-th best can matter
+  uint32_t i_next = 0;
+  if (sub == 0) i_next = atomicAdd(&s.st[ST_TMP2], 2u);
+  for (;;) {
+    const uint32_t i = row_bcast0(i_next);
+    if (i >= n_items) break;
+    // the pull for the following step is issued before this step's work
+    if (sub == 0) i_next = atomicAdd(&s.st[ST_TMP2], 2u);
+    uint32_t len[2];
+    const uint8_t* rec[2];
+    const uint8_t* val[2];
+    DocChunk<CT> d[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t iu = i + (uint32_t)u;
+      const bool has = iu < n_items;
+      const uint64_t ref = has ? cb.it_ref[iu] : 0ull;
+      const bool run = has && (cb.it_doc[has ? iu : 0] >> 31) == 0;
+      len[u] = run ? (uint32_t)(ref & 0xffffu) : 0u;
+      rec[u] = ix.fwd + (ref >> 16) * 16ull;
+      val[u] = rec[u] + (size_t)((len[u] + 7u) & ~7u) * sizeof(CT);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        d[u][h].c0 = d[u][h].c1 = d[u][h].v = make_uint4(0, 0, 0, 0);
+        if (e0 + 128u * h < len[u]) load_chunk<CT>(d[u][h], rec[u], val[u], e0 + 128u * h);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float a = 0.0f;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (e0 + 128u * h < len[u]) a = accumulate_chunk<CT, LK>(s, d[u][h], e0 + 128u * h, len[u], a);
+      for (uint32_t e = e0 + 256u; e < len[u]; e += 128u) {   // documents longer than 256
+        load_chunk<CT>(d[u][0], rec[u], val[u], e);
+        a = accumulate_chunk<CT, LK>(s, d[u][0], e, len[u], a);
+      }
+      a = reduce16(a);
+      const uint32_t iu = i + (uint32_t)u;
+      spec_docs += (sub == 0 && len[u] != 0);
+      if (sub == 0 && iu < n_items) {
+        it_score[2 * iu + 1] = a;
+        if (collect && len[u] != 0 && a > thr0) {
+          const uint32_t slot = atomicAdd(&s.st[ST_NCAND], 1u);
+          if (slot < kMaxCand) s.st[ST_CAND + slot] = iu;
+        }
+      }
+    }
+  }
+}
+
+// Replay of one round on wavefront 0 + publication of the new heap state for the next filter.
+template <int KR>
+SGPU_DEV void replay_round(RegHeap<KR>& heap, const ChunkBufs& cb, const Lds& s, const KParams& p,
+                           uint32_t n_items, uint32_t* bitmap, uint32_t& decided_blk, bool block_starts_at_0,
+                           WorkCount& wc, bool dups = false) {
+  uint32_t live_items = 0;
+  const uint32_t nc = s.st[ST_NCAND];
+  if (!p.use_bitmap && heap.len == p.k && nc <= kMaxCand) {
+    // (the heap was full when the round started: phase B collected every item that can matter)
+    replay_candidates<KR>(heap, cb, s.st, nc, p.k, p.heap_factor, decided_blk);
+    live_items = n_items;
+  } else if (p.use_bitmap) {
+    replay_chunk<KR, true>(heap, cb, n_items, p.k, p.heap_factor, bitmap, decided_blk, block_starts_at_0, wc,
+                           live_items, dups);
+  } else {
+    replay_chunk<KR, false>(heap, cb, n_items, p.k, p.heap_factor, bitmap, decided_blk, block_starts_at_0, wc,
+                            live_items, dups);
+  }
+  if (lane_id() == 0) {
+    s.st[ST_HLEN] = heap.len;
+    s.st[ST_THR] = __float_as_uint(heap.len == p.k ? heap.thr : 0.0f);
+    s.st[ST_TMP1] = live_items;
   }
 }
 
@@ -1008,89 +1111,12 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             }
             __syncthreads();
             TICK(6);
-            // (d) phase B: speculative scoring, 16 lanes per document. Groups pull documents two at a
-            // time from a shared counter (documents differ 25x in length), and fetch the first TWO
-            // 128-element slices of each document up front (a third of the documents need the second).
-            {
-              const uint32_t sub = threadIdx.x & 15;
-              float* it_score = (float*)cb.it_ref;
-              const uint32_t e0 = sub * 8u;
-              const bool collect = !p.use_bitmap && s.st[ST_HLEN] == p.k;   // heap full: only scores above the
-              const float thr0 = __uint_as_float(s.st[ST_THR]);            // current k-th best can matter
-              uint32_t i_next = 0;
-              if (sub == 0) i_next = atomicAdd(&s.st[ST_TMP2], 2u);
-              for (;;) {
-                const uint32_t i = row_bcast0(i_next);
-                if (i >= n_items) break;
-                // the pull for the following step is issued before this step's work
-                if (sub == 0) i_next = atomicAdd(&s.st[ST_TMP2], 2u);
-                uint32_t len[2];
-                const uint8_t* rec[2];
-                const uint8_t* val[2];
-                DocChunk<CT> d[2][2];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                  const uint32_t iu = i + (uint32_t)u;
-                  const bool has = iu < n_items;
-                  const uint64_t ref = has ? cb.it_ref[iu] : 0ull;
-                  const bool run = has && (cb.it_doc[has ? iu : 0] >> 31) == 0;
-                  len[u] = run ? (uint32_t)(ref & 0xffffu) : 0u;
-                  rec[u] = ix.fwd + (ref >> 16) * 16ull;
-                  val[u] = rec[u] + (size_t)((len[u] + 7u) & ~7u) * sizeof(CT);
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                  for (int h = 0; h < 2; ++h) {
-                    d[u][h].c0 = d[u][h].c1 = d[u][h].v = make_uint4(0, 0, 0, 0);
-                    if (e0 + 128u * h < len[u]) load_chunk<CT>(d[u][h], rec[u], val[u], e0 + 128u * h);
-                  }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                  float a = 0.0f;
-#pragma unroll
-                  for (int h = 0; h < 2; ++h)
-                    if (e0 + 128u * h < len[u]) a = accumulate_chunk<CT, LK>(s, d[u][h], e0 + 128u * h, len[u], a);
-                  for (uint32_t e = e0 + 256u; e < len[u]; e += 128u) {   // documents longer than 256
-                    load_chunk<CT>(d[u][0], rec[u], val[u], e);
-                    a = accumulate_chunk<CT, LK>(s, d[u][0], e, len[u], a);
-                  }
-                  a = reduce16(a);
-                  const uint32_t iu = i + (uint32_t)u;
-                  spec_docs += (sub == 0 && len[u] != 0);
-                  if (sub == 0 && iu < n_items) {
-                    it_score[2 * iu + 1] = a;
-                    if (collect && len[u] != 0 && a > thr0) {
-                      const uint32_t slot = atomicAdd(&s.st[ST_NCAND], 1u);
-                      if (slot < kMaxCand) s.st[ST_CAND + slot] = iu;
-                    }
-                  }
-                }
-              }
-            }
+            // (d) phase B: speculative scoring (score_items)
+            score_items<CT, NT, LK>(s, ix, cb, p, n_items, spec_docs);
             __syncthreads();
             TICK(7);
             // (e) exact replay on wavefront 0
-            if (wave == 0) {
-              uint32_t live_items = 0;
-              const uint32_t nc = s.st[ST_NCAND];
-              if (!p.use_bitmap && heap.len == p.k && nc <= kMaxCand) {
-                // (the heap was full when the round started: phase B collected every item that can matter)
-                replay_candidates<KR>(heap, cb, s.st, nc, p.k, p.heap_factor, decided_blk);
-                live_items = n_items;
-              } else if (p.use_bitmap)
-                replay_chunk<KR, true>(heap, cb, n_items, p.k, p.heap_factor, bitmap, decided_blk, piece == 0, wc,
-                                       live_items);
-              else
-                replay_chunk<KR, false>(heap, cb, n_items, p.k, p.heap_factor, bitmap, decided_blk, piece == 0, wc,
-                                        live_items);
-              if (lane == 0) {
-                s.st[ST_HLEN] = heap.len;
-                s.st[ST_THR] = __float_as_uint(heap.len == p.k ? heap.thr : 0.0f);
-                s.st[ST_TMP1] = live_items;
-              }
-            }
+            if (wave == 0) replay_round<KR>(heap, cb, s, p, n_items, bitmap, decided_blk, piece == 0, wc);
             __syncthreads();
             TICK(8);
           }
@@ -1101,6 +1127,53 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             if (kept * 4 >= piece_items * 3) budget = budget * 2 < p.items_max ? budget * 2 : p.items_max;
             else if (kept * 2 < piece_items) budget = budget / 2 > p.items_min ? budget / 2 : p.items_min;
           }
+        }
+      }
+
+      // ---- kNN refinement (Knn::refine, reference src/inverted_index.rs:551-593): for every document
+      // of the current top-k (snapshot, best first) its first n_knn graph neighbours are scored and
+      // pushed unless already visited. One more round through the same scoring + replay machinery;
+      // "visited" is again heap membership (or the bitmap in the counted pass).
+      if (p.n_knn && ix.knn) {
+        uint32_t* snap = cb.cb_incl;   // cb_incl + cb_p0 are contiguous: 2*NT words >= k
+        if (wave == 0) {
+#pragma unroll
+          for (int r = 0; r < KR; ++r) {
+            const uint32_t e = (uint32_t)r * 64u + lane;
+            if (e < heap.len) snap[e] = heap.doc[r];
+          }
+          if (lane == 0) s.st[ST_TMP0] = heap.len;
+        }
+        __syncthreads();
+        const uint32_t hl = s.st[ST_TMP0];
+        const uint32_t nk = p.n_knn < ix.knn_dim ? p.n_knn : ix.knn_dim;
+        const uint32_t total = hl * nk;
+        uint32_t decided_blk = 0xffffffffu;
+        for (uint32_t base = 0; base < total; base += p.items_max) {
+          const uint32_t n_items = total - base < p.items_max ? total - base : p.items_max;
+          if (threadIdx.x == 0) {
+            s.st[ST_TMP2] = 0;
+            s.st[ST_NCAND] = 0;
+          }
+          for (uint32_t i = threadIdx.x; i < n_items; i += NT) {
+            const uint32_t j = base + i;
+            const uint32_t r = j / nk, t = j - r * nk;
+            const uint64_t pos = (uint64_t)snap[r] * ix.knn_dim + t;
+            bool ok = pos < ix.knn_total;
+            const uint32_t nbr = ok ? ix.knn[pos] : 0u;
+            ok = ok && nbr < ix.n_docs;
+            const uint64_t ref = ok ? ix.doc_ref[nbr] : 0ull;
+            const bool vis = !ok || (p.use_bitmap && visited_test(bitmap, nbr));
+            cb.it_ref[i] = ref;
+            cb.it_doc[i] = nbr | (vis ? 0x80000000u : 0u);
+            cb.it_blk[i] = 0;
+            cb.it_dot[i] = __builtin_inff();   // no block test in the refinement
+          }
+          __syncthreads();
+          score_items<CT, NT, LK>(s, ix, cb, p, n_items, spec_docs);
+          __syncthreads();
+          if (wave == 0) replay_round<KR>(heap, cb, s, p, n_items, bitmap, decided_blk, true, wc, true);
+          __syncthreads();
         }
       }
     }

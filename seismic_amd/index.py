@@ -26,7 +26,9 @@ Documented deviations (DESIGN.md "Boundary"):
     does not guarantee any order, src/pylib/mod.rs:629-652);
   * num_threads is accepted and ignored on the GPU path (it is ineffective in
     the reference as well: the pool it builds is dropped, src/pylib/mod.rs:599-602);
-  * n_knn / nknn must be 0: the kNN graph is outside this path.
+  * the kNN graph (build_knn / nknn, n_knn at search time) is built ON THE GPU by searching every
+    document through the same kernel; knn files are numpy .npy (the reference's *.knn.seismic
+    uses vectorium's serializer).
 """
 import gzip
 import io
@@ -160,9 +162,10 @@ def _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy, max_fr
                                 num_threads=int(num_threads))
 
 
-def _no_knn(n):
-    if n:
-        raise ValueError("the kNN graph (nknn / n_knn > 0) is outside the GPU search path of this build")
+def _no_knn_path(knn_path):
+    if knn_path:
+        raise ValueError("precomputed *.knn.seismic files use vectorium's serializer, which is not in the "
+                         "reference tree; build the graph with nknn=... or load a .npy with load_knn()")
 
 
 # ---------------------------------------------------------------------------
@@ -240,7 +243,7 @@ class _IndexBase:
               max_fraction=1.5, doc_cut=15, nknn=0, knn_path=None, batched_indexing=None,
               input_token_to_id_map=None, load_content=True, num_threads=0, device=0, upload=True):
         """Build from a .jsonl / .jsonl.gz / .tar.gz file (reference src/pylib/mod.rs:329-384)."""
-        _no_knn(nknn or knn_path)
+        _no_knn_path(knn_path)
         ids, vecs, contents = read_jsonl(input_path)
         tm = _token_map(vecs, input_token_to_id_map)
         if cls._CW == 2 and len(tm) >= 2 ** 16:
@@ -249,19 +252,25 @@ class _IndexBase:
         ix = _native.NativeIndex.build(cls._CW, max(len(tm), 1), off, c, v,
                                        _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy,
                                             max_fraction, doc_cut, num_threads))
-        return cls(ix, tm, ids, contents if load_content else None, device, upload)
+        self = cls(ix, tm, ids, contents if load_content else None, device, upload or bool(nknn))
+        if nknn:
+            self.build_knn(nknn)
+        return self
 
     @classmethod
     def build_from_dataset(cls, dataset, n_postings=3500, centroid_fraction=0.1, min_cluster_size=2,
                            summary_energy=0.4, max_fraction=1.5, doc_cut=15, nknn=0, knn_path=None,
                            batched_indexing=None, num_threads=0, device=0, upload=True):
-        _no_knn(nknn or knn_path)
+        _no_knn_path(knn_path)
         tm = _token_map(dataset._vecs)
         off, c, v = _to_csr(dataset._vecs, tm)
         ix = _native.NativeIndex.build(cls._CW, max(len(tm), 1), off, c, v,
                                        _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy,
                                             max_fraction, doc_cut, num_threads))
-        return cls(ix, tm, list(dataset._ids), list(dataset._contents), device, upload)
+        self = cls(ix, tm, list(dataset._ids), list(dataset._contents), device, upload or bool(nknn))
+        if nknn:
+            self.build_knn(nknn)
+        return self
 
     @classmethod
     def load(cls, index_path, device=0, upload=True):
@@ -301,7 +310,29 @@ class _IndexBase:
 
     @property
     def knn_len(self):
-        return 0
+        return self._ix.get_knn()[1]
+
+    def build_knn(self, nknn):
+        """reference src/pylib/mod.rs:195-197 (build_knn). Runs on the GPU."""
+        self._ensure_device()
+        self._ix.build_knn(nknn)
+
+    def save_knn(self, path):
+        nb, dim = self._ix.get_knn()
+        if dim == 0:
+            raise ValueError("the index has no kNN graph")   # reference: PyValueError (src/pylib/mod.rs:217-221)
+        np.save(path if path.endswith(".npy") else path + ".knn.npy", np.concatenate([[dim], nb]).astype(np.uint32))
+
+    def load_knn(self, knn_path, nknn=None):
+        try:
+            a = np.load(knn_path if knn_path.endswith(".npy") else knn_path + ".knn.npy")
+        except OSError as e:
+            raise IOError(str(e))
+        dim, nb = int(a[0]), a[1:].astype(np.uint32)
+        if nknn is not None and nknn < dim and len(nb) == self.len * dim:   # keep the first nknn per document
+            nb = nb.reshape(self.len, dim)[:, :nknn].reshape(-1)
+            dim = nknn
+        self._ix.set_knn(nb, dim)
 
     def get_doc_ids_in_postings(self, list_id):
         d = self._ix.desc
@@ -341,18 +372,16 @@ class _IndexBase:
 
     def search(self, query_id, query_components, query_values, k, query_cut, heap_factor, n_knn=0, sorted=True):
         """-> [(query_id, score, doc_id)], best first (reference src/pylib/mod.rs:490-533)."""
-        _no_knn(n_knn)
         self._ensure_device()
         c, v = _resolve([str(t) for t in np.asarray(query_components).ravel()],
                         np.asarray(query_values, np.float32).ravel(), self._tm)
-        sc, ids = self._ix.search(c, v, k, query_cut, heap_factor, first_sorted=bool(sorted))
+        sc, ids = self._ix.search(c, v, k, query_cut, heap_factor, first_sorted=bool(sorted), n_knn=n_knn)
         return self._remap(query_id, sc, ids, len(ids))
 
     def batch_search(self, queries_ids, query_components, query_values, k, query_cut, heap_factor, n_knn=0,
                      sorted=True, num_threads=0):
         """-> [[(query_id, score, doc_id)]] in input order (reference src/pylib/mod.rs:572-655).
         One GPU pass over the whole batch."""
-        _no_knn(n_knn)
         self._ensure_device()
         qids = [str(x) for x in np.asarray(queries_ids).ravel()]
         off = np.zeros(len(qids) + 1, np.uint64)
@@ -364,7 +393,8 @@ class _IndexBase:
             off[i + 1] = off[i] + len(c)
         comps = np.concatenate(cs) if cs else np.zeros(0, np.uint32)
         vals = np.concatenate(vs) if vs else np.zeros(0, np.float32)
-        sc, ids, n = self._ix.batch_search(off, comps, vals, k, query_cut, heap_factor, first_sorted=bool(sorted))
+        sc, ids, n = self._ix.batch_search(off, comps, vals, k, query_cut, heap_factor, first_sorted=bool(sorted),
+                                           n_knn=n_knn)
         return [self._remap(qids[i], sc[i], ids[i], n[i]) for i in range(len(qids))]
 
 
@@ -402,7 +432,7 @@ class _RawBase:
     def build(cls, input_file, n_postings=3500, centroid_fraction=0.1, min_cluster_size=2, summary_energy=0.4,
               max_fraction=1.5, doc_cut=15, nknn=0, knn_path=None, batched_indexing=None, num_threads=0,
               device=0, upload=True):
-        _no_knn(nknn or knn_path)
+        _no_knn_path(knn_path)
         off, c, v = read_inner_format(input_file)
         dim = int(c.max()) + 1 if len(c) else 1
         if cls._CW == 2 and dim > 65536:
@@ -410,7 +440,14 @@ class _RawBase:
         ix = _native.NativeIndex.build(cls._CW, dim, off, c, v,
                                        _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy,
                                             max_fraction, doc_cut, num_threads))
-        return cls(ix, device, upload)
+        self = cls(ix, device, upload or bool(nknn))
+        if nknn:
+            self.build_knn(nknn)
+        return self
+
+    build_knn = _IndexBase.build_knn
+    save_knn = _IndexBase.save_knn
+    load_knn = _IndexBase.load_knn
 
     @classmethod
     def load(cls, index_path, device=0, upload=True):
@@ -427,19 +464,18 @@ class _RawBase:
 
     def search(self, query_components, query_values, k, query_cut, heap_factor, n_knn, sorted):
         """-> [(score, doc_id)] (reference src/pylib/mod.rs:1033-1076)."""
-        _no_knn(n_knn)
         self._ensure_device()
         sc, ids = self._ix.search(np.asarray(query_components).astype(np.uint32),
                                   np.asarray(query_values, np.float32), k, query_cut, heap_factor,
-                                  first_sorted=bool(sorted))
+                                  first_sorted=bool(sorted), n_knn=n_knn)
         return [(float(s), int(i)) for s, i in zip(sc, ids)]
 
     def batch_search(self, query_path, k, query_cut, heap_factor, n_knn, sorted, num_threads=0):
         """queries.bin in the inner format -> [[(score, doc_id)]] in file order (src/pylib/mod.rs:1098-1146)."""
-        _no_knn(n_knn)
         self._ensure_device()
         off, c, v = read_inner_format(query_path)
-        sc, ids, n = self._ix.batch_search(off, c, v, k, query_cut, heap_factor, first_sorted=bool(sorted))
+        sc, ids, n = self._ix.batch_search(off, c, v, k, query_cut, heap_factor, first_sorted=bool(sorted),
+                                           n_knn=n_knn)
         return [[(float(sc[q, i]), int(ids[q, i])) for i in range(int(n[q]))] for q in range(len(off) - 1)]
 
 

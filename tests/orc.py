@@ -106,20 +106,42 @@ def desc_arrays(desc):
     )
 
 
+def knn_build(desc, nknn):
+    """Knn::new restated: flattened neighbour ids (documents with < nknn results contribute fewer)."""
+    out = np.zeros(max(int(desc.n_docs) * nknn, 1), np.uint32)
+    lib().orc_knn_build.restype = C.c_uint64
+    n = lib().orc_knn_build(C.byref(desc), C.c_uint32(nknn), _p(out))
+    return out[: int(n)].copy()
+
+
+_KNN_KEEP = [None]
+
+
+def knn_attach(neighbours, dim):
+    """Graph used by search()/batch_search() when n_knn > 0 (None detaches)."""
+    if neighbours is None:
+        _KNN_KEEP[0] = None
+        lib().orc_knn_attach(None, C.c_uint64(0), C.c_uint32(0))
+        return
+    a = np.ascontiguousarray(neighbours, np.uint32)
+    _KNN_KEEP[0] = a
+    lib().orc_knn_attach(_p(a), C.c_uint64(len(a)), C.c_uint32(dim))
+
+
 def params(k, query_cut, heap_factor, first_sorted=False, n_knn=0):
     return SearchParams(k=k, query_cut=query_cut, heap_factor=heap_factor, n_knn=n_knn,
                         first_sorted=1 if first_sorted else 0)
 
 
 def search(desc, comps, vals, k, query_cut, heap_factor, first_sorted=False, order=ORDER_LANES16,
-           want_stats=False):
+           want_stats=False, n_knn=0):
     comps = np.ascontiguousarray(comps, np.uint32)
     vals = np.ascontiguousarray(vals, np.float32)
     sc = np.zeros(k, np.float32)
     ids = np.zeros(k, np.uint64)
     n = C.c_uint32(0)
     st = Stats()
-    p = params(k, query_cut, heap_factor, first_sorted)
+    p = params(k, query_cut, heap_factor, first_sorted, n_knn)
     rc = lib().orc_search(C.byref(desc), _p(comps), _p(vals), len(comps), C.byref(p), order, _p(sc),
                           _p(ids), C.byref(n), C.byref(st))
     if rc:
@@ -129,7 +151,7 @@ def search(desc, comps, vals, k, query_cut, heap_factor, first_sorted=False, ord
 
 
 def batch_search(desc, q_off, comps, vals, k, query_cut, heap_factor, first_sorted=False,
-                 order=ORDER_LANES16, num_threads=0):
+                 order=ORDER_LANES16, num_threads=0, n_knn=0):
     q_off = np.ascontiguousarray(q_off, np.uint64)
     comps = np.ascontiguousarray(comps, np.uint32)
     vals = np.ascontiguousarray(vals, np.float32)
@@ -140,7 +162,7 @@ def batch_search(desc, q_off, comps, vals, k, query_cut, heap_factor, first_sort
     st = Stats()
     secs = C.c_double(0)
     used = C.c_uint32(0)
-    p = params(k, query_cut, heap_factor, first_sorted)
+    p = params(k, query_cut, heap_factor, first_sorted, n_knn)
     rc = lib().orc_batch_search(C.byref(desc), _p(q_off), _p(comps), _p(vals), nq, C.byref(p), order,
                                 num_threads, _p(sc), _p(ids), _p(n), C.byref(st), C.byref(secs),
                                 C.byref(used))

@@ -99,8 +99,9 @@ def test_edge_cases():
             ix.search(bad["c"], bad["v"], 10, 5, 0.7)
     with pytest.raises(_native.SeismicHipError):
         ix.search([1], [1.0], 0, 5, 0.7)          # k == 0
-    with pytest.raises(_native.SeismicHipError):
-        ix.search([1], [1.0], 10, 5, 0.7, n_knn=3)  # no kNN graph on this path
+    # n_knn without a graph is ignored, as in the reference (src/inverted_index.rs:215-216)
+    a_, b_ = ix.search([7], [1.0], 10, 5, 0.7, n_knn=3), ix.search([7], [1.0], 10, 5, 0.7)
+    assert np.array_equal(a_[1], b_[1]) and np.array_equal(a_[0], b_[0])
     # ragged batch incl. empty queries
     q_off = np.array([0, 0, 3, 3, 40], np.uint64)
     rng = np.random.default_rng(3)
