@@ -217,7 +217,8 @@ sgpu_status sgpu_batch_fetch(sgpu_index* idx, sgpu_batch* batch, uint32_t k,
  *   [5] documents scored (as the reference would; exact after sgpu_batch_run_counted, otherwise
  *       re-encountered documents are included)   [6] sum of their component counts
  *   [7] documents the kernel scored speculatively (>= [5]; the surplus is overhead)
- *   [8..19] kernel phase clocks (shader cycles / 16), [20] workgroup slot, [21..23] reserved
+ *   [8..19] kernel phase clocks (shader cycles / 16; zero unless the library was built with
+ *           -DSGPU_PROF, `make prof`), [20] workgroup slot, [21..23] reserved
  * Counters [3..6] are exact only after sgpu_batch_run_counted (the default pass skips replay windows
  * that cannot change the heap and does not track re-encountered documents).
  * Counters [0..6] are what the ALGORITHM touches and feed the roofline accounting. */

@@ -9,6 +9,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the phase clocks exist only in the profiling build of the library (make -C seismic_amd/csrc prof)
+os.environ.setdefault("SGPU_LIB", os.path.join(ROOT, "seismic_amd", "libseismic_hip_prof.so"))
 from seismic_amd import _native  # noqa: E402
 from seismic_amd._abi import BuildConfig  # noqa: E402
 
