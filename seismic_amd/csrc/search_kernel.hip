@@ -306,88 +306,119 @@ SGPU_DEV void build_row_table(const Lds& s, const DevView& ix, uint32_t nnz, uin
 //     `* qv` and the accumulation below follow :107-108. No FMA anywhere.
 // (b) accumulate: one wavefront per list adds the products row by row, in ascending query
 //     component order, to the list's accumulators (LDS only, in-order DS pipeline).
+struct StageBuf {   // one staging buffer: products and block ids of `cap_l` entries per list
+  float* prod;
+  uint16_t* bid;
+};
+
+// copy of one window [w0, w0 + cap_l) of every list's flattened matched entries into `sb`, by
+// threads tid = 0..nthreads-1: every thread takes SU consecutive positions of one list's window
+// (one row lookup by binary search in LDS, a short forward walk for the rest), then SU independent
+// HBM loads.
+template <int SU>
+SGPU_DEV void stage_copy(const Lds& s, const DevView& ix, const StageBuf& sb, uint32_t nnz, uint32_t nl,
+                         uint32_t qn, uint32_t cap_l, uint32_t inv_cap, uint32_t w0, uint32_t tid,
+                         uint32_t nthreads) {
+  const uint32_t span = nl * cap_l;
+  for (uint32_t base = tid * SU; base < span; base += SU * nthreads) {
+    uint32_t l = __umulhi(base, inv_cap);
+    uint32_t r = base - l * cap_l;
+    if (r >= cap_l) {
+      r -= cap_l;
+      ++l;
+    }
+    const uint32_t* pre = s.rt_pre + l * (qn + 1);
+    const uint32_t* rts = s.rt_start + l * qn;
+    const uint32_t e_l = pre[nnz];
+    const uint32_t f0 = w0 + r;
+    if (f0 >= e_l) continue;
+    uint32_t lo = 0, hi = nnz;   // last row j with pre[j] <= f0
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (pre[mid] <= f0) lo = mid; else hi = mid;
+    }
+    uint32_t g[SU];
+    float qv[SU];
+    bool ok[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const uint32_t f = f0 + (uint32_t)u;
+      ok[u] = f < e_l;
+      while (lo + 1 < nnz && pre[lo + 1] <= f) ++lo;
+      g[u] = ok[u] ? rts[lo] + (f - pre[lo]) : 0u;
+      qv[u] = s.q_val[lo];
+    }
+    uint32_t bid[SU];
+    float deq[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      bid[u] = ok[u] ? (uint32_t)ix.sum_bid[g[u]] : 0u;
+      deq[u] = ok[u] ? ix.sum_deq[g[u]] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      if (ok[u]) {
+        sb.prod[base + (uint32_t)u] = __fmul_rn(deq[u], qv[u]);
+        sb.bid[base + (uint32_t)u] = (uint16_t)bid[u];
+      }
+    }
+  }
+}
+
+// one wavefront adds list l's staged window to its accumulators, row by row in ascending query
+// component order. Block ids are distinct within a row, so lanes never collide; a wavefront's DS
+// operations execute in issue order, so each accumulator sees the reference's order of additions.
+SGPU_DEV void stage_accumulate(const Lds& s, const StageBuf& sb, uint32_t nnz, uint32_t qn, uint32_t cap_l,
+                               uint32_t w0, uint32_t l) {
+  const uint32_t lane = threadIdx.x & 63;
+  float* acc = s.dots + s.sel_doff[l];
+  const float* sp = sb.prod + l * cap_l;
+  const uint16_t* sbid = sb.bid + l * cap_l;
+  const uint32_t* pre = s.rt_pre + l * (qn + 1);
+  for (uint32_t j = 0; j < nnz; ++j) {
+    const uint32_t p0 = pre[j], p1 = pre[j + 1];
+    const uint32_t a = p0 > w0 ? p0 : w0;
+    const uint32_t b = p1 < w0 + cap_l ? p1 : w0 + cap_l;
+    for (uint32_t f = a + lane; f < b; f += 64) {
+      const uint32_t bid = sbid[f - w0];
+      acc[bid] = __fadd_rn(acc[bid], sp[f - w0]);
+    }
+  }
+}
+
+// Computes dots for lists [0, nl). stage_cap = staging entries (6 bytes each) available from the
+// start of the lookup-table region to the end of the union region (the lookup table is only
+// needed in stage 2 and is rebuilt after this stage).
+//   copy      : the matched rows' (block id, dequantised value) entries stream from HBM, are
+//               multiplied by the query weight and parked in LDS. The value array holds
+//               code*quant + min computed once at upload with the reference's roundings
+//               (src/quantized_summary.rs:102-104); `* qv` and `+=` follow :107-108. No FMA.
+//   accumulate: one wavefront per list (stage_accumulate).
+// (Measured and dropped: splitting the staging area in two so that half the wavefronts copy window
+// r + 1 while the others accumulate window r — the copy, not the accumulation, is the long pole.)
 template <int NT>
 SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32_t nl, uint32_t qn,
                            uint32_t stage_cap) {
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t wave = threadIdx.x >> 6;
   constexpr uint32_t NW = NT / 64;
   constexpr int SU = 8;
   const uint32_t total_blocks = s.sel_doff[nl];
   for (uint32_t i = threadIdx.x; i < total_blocks; i += NT) s.dots[i] = 0.0f;
-  const uint32_t cap_l = (stage_cap / nl) & ~63u;   // staging window per list
-  const uint32_t inv_cap = 0xffffffffu / cap_l;
-  float* st_prod = (float*)s.stage;
-  uint16_t* st_bid = (uint16_t*)(st_prod + (size_t)cap_l * nl);
   uint32_t emax = 0;
   for (uint32_t l = 0; l < nl; ++l) {
     const uint32_t e = s.rt_pre[l * (qn + 1) + nnz];
     emax = e > emax ? e : emax;
   }
+  const uint32_t cap_l = (stage_cap / nl) & ~63u;   // staging window per list
+  const uint32_t inv_cap = 0xffffffffu / cap_l;
+  StageBuf sb;
+  sb.prod = (float*)s.stage;
+  sb.bid = (uint16_t*)(sb.prod + (size_t)cap_l * nl);
   __syncthreads();
   for (uint32_t w0 = 0; w0 < emax; w0 += cap_l) {
-    const uint32_t span = nl * cap_l;
-    // every thread takes SU consecutive positions of one list's window: one row lookup (binary
-    // search in LDS) for the first, a short forward walk for the rest, then SU independent HBM loads
-    for (uint32_t base = threadIdx.x * SU; base < span; base += SU * NT) {
-      uint32_t l = __umulhi(base, inv_cap);
-      uint32_t r = base - l * cap_l;
-      if (r >= cap_l) {
-        r -= cap_l;
-        ++l;
-      }
-      const uint32_t* pre = s.rt_pre + l * (qn + 1);
-      const uint32_t* rts = s.rt_start + l * qn;
-      const uint32_t e_l = pre[nnz];
-      const uint32_t f0 = w0 + r;
-      uint32_t lo = 0, hi = nnz;   // last row j with pre[j] <= f0
-      while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (pre[mid] <= f0) lo = mid; else hi = mid;
-      }
-      uint32_t g[SU];
-      float qv[SU];
-      bool ok[SU];
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        const uint32_t f = f0 + (uint32_t)u;
-        ok[u] = f < e_l;
-        while (lo + 1 < nnz && pre[lo + 1] <= f) ++lo;
-        g[u] = ok[u] ? rts[lo] + (f - pre[lo]) : 0u;
-        qv[u] = s.q_val[lo];
-      }
-      uint32_t bid[SU];
-      float deq[SU];
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        bid[u] = ok[u] ? (uint32_t)ix.sum_bid[g[u]] : 0u;
-        deq[u] = ok[u] ? ix.sum_deq[g[u]] : 0.0f;
-      }
-#pragma unroll
-      for (int u = 0; u < SU; ++u) {
-        if (ok[u]) {
-          st_prod[base + (uint32_t)u] = __fmul_rn(deq[u], qv[u]);
-          st_bid[base + (uint32_t)u] = (uint16_t)bid[u];
-        }
-      }
-    }
+    stage_copy<SU>(s, ix, sb, nnz, nl, qn, cap_l, inv_cap, w0, threadIdx.x, NT);
     __syncthreads();
-    for (uint32_t l = wave; l < nl; l += NW) {
-      float* acc = s.dots + s.sel_doff[l];
-      const float* sp = st_prod + l * cap_l;
-      const uint16_t* sb = st_bid + l * cap_l;
-      const uint32_t* pre = s.rt_pre + l * (qn + 1);
-      for (uint32_t j = 0; j < nnz; ++j) {
-        const uint32_t p0 = pre[j], p1 = pre[j + 1];
-        const uint32_t a = p0 > w0 ? p0 : w0;
-        const uint32_t b = p1 < w0 + cap_l ? p1 : w0 + cap_l;
-        // block ids are distinct within a row, so lanes never collide; rows are applied
-        // in order and a wavefront's DS operations execute in issue order.
-        for (uint32_t f = a + lane; f < b; f += 64) {
-          const uint32_t bid = sb[f - w0];
-          acc[bid] = __fadd_rn(acc[bid], sp[f - w0]);
-        }
-      }
-    }
+    for (uint32_t l = wave; l < nl; l += NW) stage_accumulate(s, sb, nnz, qn, cap_l, w0, l);
     __syncthreads();
   }
 }
