@@ -650,6 +650,12 @@ sgpu_status device_index_set_knn(DeviceIndex* d, const std::vector<uint32_t>& kn
   std::lock_guard<std::mutex> lock(d->mu);
   HIP_TRY(hipSetDevice(d->device));
   HIP_TRY(hipStreamSynchronize(d->stream));
+  if (d->view.knn) {   // drop the previous graph's device copy
+    auto it = std::find(d->allocs.begin(), d->allocs.end(), (void*)d->view.knn);
+    if (it != d->allocs.end()) d->allocs.erase(it);
+    (void)hipFree((void*)d->view.knn);
+    d->bytes -= std::min<uint64_t>(d->bytes, d->view.knn_total * 4);
+  }
   d->view.knn = nullptr;
   d->view.knn_total = 0;
   d->view.knn_dim = 0;

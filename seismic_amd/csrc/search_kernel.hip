@@ -63,9 +63,6 @@ namespace sgpu {
 #ifndef SGPU_WAVES_PER_EU
 #define SGPU_WAVES_PER_EU 4   // 2 workgroups of 512 threads per CU (<= 128 VGPRs)
 #endif
-#ifndef SGPU_DU
-#define SGPU_DU 2             // documents in flight per 16-lane group in phase B
-#endif
 
 // ---------------------------------------------------------------------------
 // small helpers
@@ -1124,7 +1121,7 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
               n_items = cb.cb_incl[nblk - 1];
             }
             piece_items = n_items;
-            // (c) phase A: posting refs + visited bits (thread per item)
+            // (c) phase A: posting refs (thread per item; + visited bits in the counted pass)
             if (threadIdx.x == 0) {
               s.st[ST_TMP2] = 0;    // phase B's item counter
               s.st[ST_NCAND] = 0;   // phase B's candidate counter
