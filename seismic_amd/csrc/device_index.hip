@@ -89,9 +89,8 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
   if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
     return fail(SGPU_EDEVICE, "no HIP device available (the search path has no CPU fallback)");
   if (device < 0 || device >= n_dev) return fail(SGPU_EDEVICE, "device %d out of range (0..%d)", device, n_dev - 1);
-  if (h.n_blocks() >= 0xffffffffull || h.n_postings() >= 0xffffffffull || h.n_rows() >= 0xffffffffull ||
-      h.n_entries() >= 0xffffffffull)
-    return fail(SGPU_ELIMIT, "index too large for 32-bit device offsets");
+  if (h.n_blocks() >= 0xffffffffull || h.n_postings() >= 0xffffffffull || h.n_rows() >= 0xffffffffull)
+    return fail(SGPU_ELIMIT, "index too large for 32-bit device offsets (blocks / postings / summary rows)");
   HIP_TRY(hipSetDevice(device));
   DeviceIndex* d = new DeviceIndex();
   d->device = device;
@@ -173,8 +172,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       if ((st = dev_copy(d, v.data(), v.size(), &d->view.block_post_start)) != SGPU_OK) return bail(st);
       v = narrow(h.list_row_start);
       if ((st = dev_copy(d, v.data(), v.size(), &d->view.list_row_start)) != SGPU_OK) return bail(st);
-      v = narrow(h.row_ptr);
-      if ((st = dev_copy(d, v.data(), v.size(), &d->view.row_ptr)) != SGPU_OK) return bail(st);
+      if ((st = dev_copy(d, h.row_ptr.data(), h.row_ptr.size(), &d->view.row_ptr)) != SGPU_OK) return bail(st);
     }
     {
       const uint8_t* rc = nullptr;
@@ -416,7 +414,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   L.q_comp = o; o += up16(qn * 4);
   L.q_val = o; o += up16((qn + 1) * 4);   // + the 0.0 slot non-matching components resolve to
   L.sel = o; o += up16((6 * qc + 1) * 4);
-  L.rt_start = o; o += up16(qc * qn * 4);
+  L.rt_start = o; o += up16(qc * qn * 8);
   L.rt_pre = o; o += up16(qc * (qn + 1) * 4);
   L.dots = o; o += up16(dots_cap * 4);
   L.order = o; o += up16((sp.first_sorted && searching) ? sort_nb * 2 : 0);

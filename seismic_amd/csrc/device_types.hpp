@@ -17,7 +17,7 @@ struct DevView {
   const uint32_t* post_doc;           // n_postings: document id (visited set key, result id)
   const uint32_t* list_row_start;     // dim + 1
   const void* row_comp;               // n_rows, ascending within a list
-  const uint32_t* row_ptr;            // n_rows + 1
+  const uint64_t* row_ptr;            // n_rows + 1 (entries can exceed 2^32 on large indexes)
   const uint16_t* sum_bid;            // n_entries: list-local block id
   const float* sum_deq;               // n_entries: code*quant + min of the entry's block, rounded as the
                                       //   reference does (src/quantized_summary.rs:102-104), precomputed at upload

@@ -134,7 +134,7 @@ struct Lds {
   uint32_t* sel_doff;   // [QC+1] offset of the list's dots in `dots`
   uint32_t* sel_r0;     // [QC] first global summary row
   uint32_t* sel_nr;     // [QC] number of summary rows
-  uint32_t* rt_start;   // [QC*QN] global entry index of matched row (l, j)
+  uint64_t* rt_start;   // [QC*QN] global entry index of matched row (l, j) (64-bit: > 4 G summary entries)
   uint32_t* rt_pre;     // [QC*(QN+1)] flattened prefix of matched row lengths
   float* dots;
   uint16_t* order;
@@ -161,7 +161,7 @@ SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
   l.sel_doff = l.sel_b0 + L.qc;          // qc + 1
   l.sel_r0 = l.sel_doff + L.qc + 1;
   l.sel_nr = l.sel_r0 + L.qc;
-  l.rt_start = (uint32_t*)(smem + L.rt_start);
+  l.rt_start = (uint64_t*)(smem + L.rt_start);
   l.rt_pre = (uint32_t*)(smem + L.rt_pre);
   l.dots = (float*)(smem + L.dots);
   l.order = (uint16_t*)(smem + L.order);
@@ -254,10 +254,11 @@ SGPU_DEV void build_row_table(const Lds& s, const DevView& ix, uint32_t nnz, uin
       const uint32_t c = (uint32_t)row_comp[mid];
       if (c < target) lo = mid + 1; else hi = mid;
     }
-    uint32_t start = 0, len = 0;
+    uint64_t start = 0;
+    uint32_t len = 0;
     if (lo < s.sel_r0[l] + s.sel_nr[l] && (uint32_t)row_comp[lo] == target) {
       start = ix.row_ptr[lo];
-      len = ix.row_ptr[lo + 1] - start;
+      len = (uint32_t)(ix.row_ptr[lo + 1] - start);
     }
     s.rt_start[l * qn + j] = start;
     s.rt_pre[l * (qn + 1) + j + 1] = len;   // turned into a prefix below
@@ -325,7 +326,7 @@ SGPU_DEV void stage_copy(const Lds& s, const DevView& ix, const StageBuf& sb, ui
       ++l;
     }
     const uint32_t* pre = s.rt_pre + l * (qn + 1);
-    const uint32_t* rts = s.rt_start + l * qn;
+    const uint64_t* rts = s.rt_start + l * qn;
     const uint32_t e_l = pre[nnz];
     const uint32_t f0 = w0 + r;
     if (f0 >= e_l) continue;
@@ -334,7 +335,7 @@ SGPU_DEV void stage_copy(const Lds& s, const DevView& ix, const StageBuf& sb, ui
       const uint32_t mid = (lo + hi) >> 1;
       if (pre[mid] <= f0) lo = mid; else hi = mid;
     }
-    uint32_t g[SU];
+    uint64_t g[SU];
     float qv[SU];
     bool ok[SU];
 #pragma unroll
@@ -342,7 +343,7 @@ SGPU_DEV void stage_copy(const Lds& s, const DevView& ix, const StageBuf& sb, ui
       const uint32_t f = f0 + (uint32_t)u;
       ok[u] = f < e_l;
       while (lo + 1 < nnz && pre[lo + 1] <= f) ++lo;
-      g[u] = ok[u] ? rts[lo] + (f - pre[lo]) : 0u;
+      g[u] = ok[u] ? rts[lo] + (f - pre[lo]) : 0ull;
       qv[u] = s.q_val[lo];
     }
     uint32_t bid[SU];
