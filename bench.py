@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--comp-width", type=int, default=2, choices=[2, 4])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-recall", action="store_true", help="skip recall@k vs exact")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget per mode")
     ap.add_argument("--index-cache", default=os.environ.get("SGPU_INDEX_CACHE", ""))
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -177,7 +178,7 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
     out = {
-        "metric": "queries/sec at fixed recall@10 vs exact (Seismic search hot path, SPLADE-shape synthetic)",
+        "metric": "queries/sec + mean latency (\u00b5s) at fixed recall@10 vs exact, SPLADE-v3 MSMARCO",
         "value": qps,
         "unit": "queries/s",
         "n_gpus": world,
@@ -188,7 +189,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 scores over f16 doc values, u8 summaries, u%d components" % (8 * args.comp_width),
+        "dtype": "f32",
         "data": "synthetic",
         "config": {
             "workload": "Synthetic SPLADE-shape: %d docs, %d vocab, ~120 nnz/doc, %d queries/GPU, k=%d, 1xMI355X per rank"
@@ -200,6 +201,7 @@ def main():
                       "n_postings_kept": int(d.n_postings), "summary_entries": int(d.n_entries)},
             "query": {"k": args.k, "query_cut": args.query_cut, "heap_factor": args.heap_factor,
                       "first_sorted": bool(args.first_sorted)},
+            "storage": "f16 document values, u%d components, u8-quantised block summaries" % (8 * args.comp_width),
             "parallelism": "index replicated, %d query batch(es) of %d, no collective" % (world, args.queries),
             "launch": {"grid": int(batch.sync_stats.grid), "block": int(batch.sync_stats.block),
                        "lds_bytes": int(batch.sync_stats.lds_bytes)},
@@ -222,6 +224,23 @@ def main():
         },
         "timing_s": {"generate": t_gen, "build": t_build, "upload": t_up},
     }
+    if rank == 0 and not args.no_latency:
+        # mean latency of batch-1 searches (the reference's AQT: one query at a time,
+        # src/bin/perf_inverted_index.rs:184-216): resident single-query batches, one synchronous
+        # kernel pass each; wall time around launch + completion.
+        nlat = min(200, args.queries)
+        singles = [_native.DeviceBatch(index, np.array([0, q_off[i + 1] - q_off[i]], np.uint64),
+                                       q_comp[q_off[i]:q_off[i + 1]], q_val[q_off[i]:q_off[i + 1]], args.k)
+                   for i in range(nlat)]
+        for sb in singles[:10]:
+            sb.run(args.k, args.query_cut, args.heap_factor, bool(args.first_sorted), sync=True)
+        t0 = time.perf_counter()
+        kms = 0.0
+        for sb in singles:
+            kms += sb.run(args.k, args.query_cut, args.heap_factor, bool(args.first_sorted), sync=True).kernel_ms
+        out["mean_latency_us_single_query"] = (time.perf_counter() - t0) * 1e6 / nlat
+        out["mean_kernel_us_single_query"] = kms * 1e3 / nlat
+        del singles
     if rank == 0 and not args.no_recall:
         t0 = time.time()
         es, ei, en = index.exact_search(q_off, q_comp, q_val, args.k)

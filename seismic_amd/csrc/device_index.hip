@@ -396,7 +396,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   const bool searching = mode != MODE_DOTS;
   const uint32_t qc = std::max<uint32_t>(1, std::min<uint32_t>(mode == MODE_DOTS ? 1u : sp.query_cut, qn));
   const uint32_t words = (d->view.dim + 31) / 32;
-  const uint32_t items_max = env_u32("SGPU_ITEMS_MAX", 1024);
+  uint32_t items_max = env_u32("SGPU_ITEMS_MAX", 1024);
   uint32_t dots_cap = 1, sort_nb = 0;
   const uint32_t* d_order = nullptr;
   if (mode == MODE_DOTS) {
@@ -422,7 +422,6 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   L.st = o; o += up16(136 * 4);   // state words + candidate lists (ST_WORDS)
   // [lookup table | union region]: stage 1 uses both as one staging area (the lookup table is
   // built after stage 1); stage 2 uses the lookup table + the union region (sort keys, item tables).
-  const uint32_t chunk_bytes = items_max * 18 + NT * 12;
   uint32_t sort_bytes = 0;
   if (sp.first_sorted && searching && sort_nb > 1) {
     uint32_t n2 = 1;
@@ -431,16 +430,28 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   }
   const uint32_t lds_limit = std::min<uint32_t>(d->max_lds ? d->max_lds : 65536, 160 * 1024);
   const uint32_t budget = env_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
-  const uint32_t min_uni = up16(std::max(chunk_bytes, sort_bytes));
   // query lookup table: dense u8 index (1 B per vocabulary id + the padding sentinel) when it is
   // allowed and fits at 2 workgroups per CU, else {bits, rank} per 32 vocabulary ids
   const uint32_t dense_bytes = up16(d->view.dim + 1), bitmap_bytes = up16(words * 8);
   const bool dense_ok = d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255 &&
                         !env_u32("SGPU_NO_DENSE", 0) && searching;
+  const uint32_t split_bits = up16(words * 4), split_bytes = split_bits + up16(words * 2);
+  // the round's item tables shrink (down to 256 items) if that is what keeps 2 workgroups per CU
+  auto uni_for = [&](uint32_t items) { return up16(std::max(items * 18 + NT * 12, sort_bytes)); };
+  const uint32_t smallest_lookup = (d->comp_width == 4) ? split_bytes : bitmap_bytes;
+  if (!std::getenv("SGPU_ITEMS_MAX")) {
+    const uint32_t want = items_max;
+    if (dense_ok)   // the dense table is worth smaller rounds (down to 512 items)
+      while (items_max > 512 && o + dense_bytes + uni_for(items_max) > budget) items_max -= 128;
+    if (!dense_ok || o + dense_bytes + uni_for(items_max) > budget) {
+      items_max = want;
+      while (items_max > 256 && o + smallest_lookup + uni_for(items_max) > budget) items_max -= 128;
+    }
+  }
+  const uint32_t min_uni = uni_for(items_max);
   const bool dense = dense_ok && (o + dense_bytes + min_uni <= budget || env_u32("SGPU_FORCE_DENSE", 0));
   // large vocabularies: bits + 16-bit ranks (6 B per 32 ids) when the packed table (8 B) would
   // cost the second workgroup per CU
-  const uint32_t split_bits = up16(words * 4), split_bytes = split_bits + up16(words * 2);
   const bool split = !dense && d->comp_width == 4 && b->max_nnz <= 65535 &&
                      (o + bitmap_bytes + min_uni > budget || env_u32("SGPU_FORCE_SPLIT", 0)) &&
                      !env_u32("SGPU_NO_SPLIT", 0);
