@@ -1,0 +1,78 @@
+"""Seeded differential fuzzing: random datasets / build parameters / search parameters, GPU vs oracle,
+bit-exact. Includes tie-heavy data (values from a tiny set), negative weights, k around the 64-lane
+register boundaries, heap_factor 0 and > 1, sorted / unsorted, kNN refinement."""
+import numpy as np
+import pytest
+
+import orc
+from seismic_amd import _native
+from seismic_amd._abi import BuildConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(rng, n_docs, dim, nnz_lo, nnz_hi, values):
+    vecs = []
+    for d in range(n_docs):
+        if rng.random() < 0.02:
+            vecs.append((np.zeros(0, np.uint32), np.zeros(0, np.float32)))
+            continue
+        n = int(rng.integers(nnz_lo, min(nnz_hi, dim) + 1))
+        c = np.sort(rng.choice(dim, n, replace=False)).astype(np.uint32)
+        vecs.append((c, values(rng, n)))
+    return orc.csr(vecs)
+
+
+def _queries(rng, nq, dim, nnz_hi, values):
+    vecs = []
+    for _ in range(nq):
+        n = int(rng.integers(0, min(nnz_hi, dim) + 1))
+        c = np.sort(rng.choice(dim, n, replace=False)).astype(np.uint32)
+        vecs.append((c, values(rng, n)))
+    return orc.csr(vecs)
+
+
+VALUE_LAWS = {
+    "exp": lambda rng, n: (rng.exponential(0.5, n) + 0.01).astype(np.float32),
+    "ties": lambda rng, n: rng.choice([0.5, 1.0, 2.0], n).astype(np.float32),
+    "signed": lambda rng, n: rng.normal(0, 1, n).astype(np.float32),
+}
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_differential(seed):
+    rng = np.random.default_rng(1000 + seed)
+    law = ["exp", "ties", "signed"][seed % 3]
+    values = VALUE_LAWS[law]
+    cw = 4 if seed % 5 == 4 else 2
+    dim = int(rng.choice([24, 100, 700, 3000])) if cw == 2 else int(rng.choice([70000, 150000]))
+    n_docs = int(rng.integers(60, 2500))
+    off, comps, vals = _dataset(rng, n_docs, dim, 1, int(rng.choice([8, 40, 200, 400])), values)
+    cfg = dict(n_postings=int(rng.choice([1, 3, 20, 200])), centroid_fraction=float(rng.choice([0.02, 0.1, 0.3, 0.6])),
+               summary_energy=float(rng.choice([0.2, 0.5, 0.9, 1.0])), max_fraction=float(rng.choice([1.0, 1.5, 6.0])),
+               min_cluster_size=int(rng.integers(0, 6)), doc_cut=int(rng.choice([1, 5, 15])))
+    ix = _native.NativeIndex.build(cw, dim, off, comps, vals, BuildConfig.defaults(**cfg)).upload(0)
+    graph = None
+    if seed % 2 == 0:
+        nknn = int(rng.integers(1, 6))
+        graph = orc.knn_build(ix.desc, nknn)
+        ix.set_knn(graph, nknn)
+        orc.knn_attach(graph, nknn)
+    try:
+        q = _queries(rng, 30, dim, int(rng.choice([5, 40, 120])), values)
+        for _ in range(4):
+            k = int(rng.choice([1, 3, 10, 63, 64, 65, 128, 129, 300]))
+            qcut = int(rng.integers(1, 13))
+            hf = float(rng.choice([0.0, 0.5, 0.8, 1.0, 1.3]))
+            srt = bool(rng.integers(0, 2))
+            n_knn = int(rng.integers(0, 8)) if graph is not None else 0
+            gs, gi, gn = ix.batch_search(*q, k, qcut, hf, srt, n_knn=n_knn)
+            cs, ci, cn, _, _, _ = orc.batch_search(ix.desc, *q, k, qcut, hf, srt, n_knn=n_knn)
+            ctx = (seed, law, cfg, k, qcut, hf, srt, n_knn)
+            assert np.array_equal(gn, cn), ctx
+            for i in range(len(gn)):
+                n = int(gn[i])
+                assert np.array_equal(gi[i, :n], ci[i, :n]), (ctx, i, gi[i, :n], ci[i, :n], gs[i, :n], cs[i, :n])
+                assert np.array_equal(gs[i, :n].view(np.uint32), cs[i, :n].view(np.uint32)), (ctx, i)
+    finally:
+        orc.knn_attach(None, 0)
