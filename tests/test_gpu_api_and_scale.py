@@ -61,6 +61,8 @@ def test_golden_synth_small_on_gpu():
 @pytest.mark.parametrize("env", [
     dict(SGPU_ITEMS_MAX="64", SGPU_ITEMS_INIT="16", SGPU_ITEMS_MIN="16", SGPU_RBLOCKS="1"),   # many rounds, oversize blocks
     dict(SGPU_NO_DENSE="1"),
+    dict(SGPU_BLOCK="512"),
+    dict(SGPU_BLOCK="512", SGPU_ITEMS_MAX="128", SGPU_ITEMS_INIT="32", SGPU_ITEMS_MIN="32"),
     dict(SGPU_FORCE_SPLIT="1"),
     dict(SGPU_BLOCK="1024", SGPU_STAGE_BYTES="8192"),                                        # many staging windows
     dict(SGPU_NO_LPT="1", SGPU_ITEMS_INIT="1024"),

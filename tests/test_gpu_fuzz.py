@@ -40,7 +40,10 @@ VALUE_LAWS = {
 
 
 @pytest.mark.parametrize("seed", range(14))
-def test_differential(seed):
+def test_differential(seed, monkeypatch):
+    # small batches default to 1024-thread workgroups; odd seeds force the 512-thread configuration
+    if seed % 2:
+        monkeypatch.setenv("SGPU_BLOCK", "512")
     rng = np.random.default_rng(1000 + seed)
     law = ["exp", "ties", "signed"][seed % 3]
     values = VALUE_LAWS[law]

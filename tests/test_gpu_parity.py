@@ -55,7 +55,9 @@ def test_kat_rust_usage_gpu():
 
 @pytest.mark.parametrize("cw,dim", [(2, 300), (4, 70000)])
 @pytest.mark.parametrize("first_sorted", [False, True])
-def test_search_matches_oracle_small(cw, dim, first_sorted):
+@pytest.mark.parametrize("block", ["512", "1024"])
+def test_search_matches_oracle_small(cw, dim, first_sorted, block, monkeypatch):
+    monkeypatch.setenv("SGPU_BLOCK", block)
     off, comps, vals = random_dataset(11, 4000, dim, nnz_lo=8, nnz_hi=200, empty_every=97)
     ix = _gpu_index(cw, dim, off, comps, vals, n_postings=60 if dim == 300 else 1, centroid_fraction=0.2,
                     summary_energy=0.5, max_fraction=6.0)
