@@ -111,14 +111,20 @@ def main():
     t_gen = time.time() - t0
     t_build = 0.0
     if rank == 0:
+        index = None
         if os.path.exists(path):
-            index = _native.NativeIndex.load(path)
-        else:
+            try:
+                index = _native.NativeIndex.load(path)
+            except _native.SeismicHipError:   # a stale / truncated file from an interrupted run
+                index = None
+        if index is None:
             t0 = time.time()
             index = _native.NativeIndex.build(args.comp_width, args.dim, *docs, cfg)
             t_build = time.time() - t0
             if world > 1 or args.index_cache:
-                index.save(path)
+                tmp = "%s.tmp.%d" % (path, os.getpid())
+                index.save(tmp)
+                os.replace(tmp, path)     # the other ranks only ever see a complete file
         log("[bench] docs generated in %.1fs, index built in %.1fs" % (t_gen, t_build))
     barrier()
     if rank != 0:
