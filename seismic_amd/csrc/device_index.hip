@@ -115,11 +115,25 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
   try {
     const uint32_t cw = h.comp_width;
     // ---- document records: [npad comps][npad f16], npad = len rounded up to 8, 16-byte aligned
+    // A record is moved to the next 128-byte line only if it would otherwise touch more lines than
+    // its size needs: at 16-byte alignment a 480-byte record straddles ~4.75 lines, line-fitted 4
+    // (less HBM traffic per scored document; the run time is the same).
     std::vector<uint64_t> rec_off16(h.n_docs + 1, 0);
-    for (uint64_t doc = 0; doc < h.n_docs; ++doc) {
-      const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
-      const uint64_t npad = (len + 7) & ~7ull;
-      rec_off16[doc + 1] = rec_off16[doc] + npad * (cw + 2) / 16;
+    {
+      const char* env_line = std::getenv("SGPU_REC_LINE");
+      const uint64_t line16 = std::max<uint64_t>(16, env_line ? std::strtoul(env_line, nullptr, 10) : 128) / 16;
+      uint64_t cur = 0;
+      for (uint64_t doc = 0; doc < h.n_docs; ++doc) {
+        const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
+        const uint64_t npad = (len + 7) & ~7ull;
+        const uint64_t size16 = npad * (cw + 2) / 16;
+        const uint64_t in_line = cur % line16;
+        if (size16 && (in_line + size16 + line16 - 1) / line16 > (size16 + line16 - 1) / line16)
+          cur += line16 - in_line;
+        rec_off16[doc] = cur;
+        cur += size16;
+      }
+      rec_off16[h.n_docs] = cur;
     }
     if (rec_off16[h.n_docs] >= (1ull << 48)) return bail(fail(SGPU_ELIMIT, "forward index exceeds 48-bit record offsets"));
     std::vector<uint8_t> fwd(std::max<uint64_t>(rec_off16[h.n_docs] * 16, 16), 0);
