@@ -1,4 +1,5 @@
 // abi.cpp — the extern "C" surface declared in include/seismic_hip.h.
+#include <mutex>
 #include <new>
 
 #include "host_index.hpp"
@@ -22,6 +23,7 @@ sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out);
 sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list, const uint32_t* comps,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
 int device_count();
+sgpu_batch** device_index_scratch_batch(DeviceIndex* d);
 sgpu_status device_index_set_knn(DeviceIndex* d, const std::vector<uint32_t>& knn, uint32_t knn_dim);
 sgpu_status build_knn_on_device(DeviceIndex* d, HostIndex& h, uint32_t nknn);
 }  // namespace sgpu
@@ -142,6 +144,7 @@ void sgpu_index_destroy(sgpu_index* idx) {
 sgpu_status sgpu_batch_create(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals,
                               uint32_t nq, uint32_t k_max, sgpu_batch** out) {
   if (!idx || !q_off || !out || (q_off[nq] && (!comps || !vals))) return fail(SGPU_EINVAL, "null argument");
+  *out = nullptr;
   return batch_create(idx->dev, idx->host.dim, q_off, comps, vals, nq, k_max, out);
 }
 
@@ -180,12 +183,17 @@ sgpu_status sgpu_batch_search(sgpu_index* idx, const uint64_t* q_off, const uint
                               uint64_t* out_doc_ids, uint32_t* out_n) {
   if (!idx || !params || !q_off || !out_scores || !out_doc_ids || !out_n) return fail(SGPU_EINVAL, "null argument");
   if (params->k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
-  sgpu_batch* b = nullptr;
-  sgpu_status st = sgpu_batch_create(idx, q_off, comps, vals, nq, params->k, &b);
+  if (!idx->dev) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
+  if (q_off[nq] && (!comps || !vals)) return fail(SGPU_EINVAL, "null argument");
+  // one recycled device batch per index: a call costs the H2D of the queries, one kernel pass and
+  // the D2H of the results, no allocation (calls on one index are serialised by this mutex)
+  static std::mutex scratch_mu;
+  std::lock_guard<std::mutex> lock(scratch_mu);
+  sgpu_batch** slot = device_index_scratch_batch(idx->dev);
+  sgpu_status st = batch_create(idx->dev, idx->host.dim, q_off, comps, vals, nq, params->k, slot);
   if (st != SGPU_OK) return st;
-  st = batch_run(idx->dev, b, *params, 0, 1, nullptr);
-  if (st == SGPU_OK) st = batch_fetch(idx->dev, b, params->k, out_scores, out_doc_ids, out_n);
-  batch_free(b);
+  st = batch_run(idx->dev, *slot, *params, 0, 1, nullptr);
+  if (st == SGPU_OK) st = batch_fetch(idx->dev, *slot, params->k, out_scores, out_doc_ids, out_n);
   return st;
 }
 

@@ -21,6 +21,11 @@ hipError_t occupancy_search(const LaunchArgs& a, int* blocks_per_cu);   // searc
       return fail(SGPU_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+}  // namespace sgpu
+struct sgpu_batch;
+namespace sgpu {
+void batch_free(sgpu_batch* b);
+
 struct DeviceIndex {
   int device = -1;
   hipStream_t stream = nullptr;
@@ -33,6 +38,7 @@ struct DeviceIndex {
   std::vector<uint32_t> list_nb, list_np;   // blocks / postings per posting list (host copy)
   uint32_t max_nb = 0;
   // per-launch scratch
+  sgpu_batch* scratch = nullptr;   // recycled by sgpu_search / sgpu_batch_search
   uint32_t* queue = nullptr;
   uint32_t* bitmaps = nullptr;
   uint32_t bitmaps_slots = 0;
@@ -63,6 +69,7 @@ void device_index_free(DeviceIndex* d) {
   if (!d) return;
   if (d->device >= 0) (void)hipSetDevice(d->device);
   if (d->stream) (void)hipStreamSynchronize(d->stream);
+  if (d->scratch) batch_free(d->scratch);
   for (void* p : d->allocs) (void)hipFree(p);
   if (d->queue) (void)hipFree(d->queue);
   if (d->bitmaps) (void)hipFree(d->bitmaps);
@@ -255,6 +262,7 @@ struct sgpu_batch {
   std::vector<sgpu_batch_plan> plans;
   int device = -1;
   uint32_t nq = 0, k_max = 0, max_nnz = 0;
+  uint64_t cap_nq = 0, cap_nnz = 0, cap_slab = 0;   // allocated capacities (a scratch batch is reused)
   uint32_t* q_off = nullptr;
   uint32_t* q_comp = nullptr;
   float* q_val = nullptr;
@@ -318,27 +326,45 @@ sgpu_status batch_create(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, co
   sgpu_status st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz);
   if (st != SGPU_OK) return st;
   HIP_TRY(hipSetDevice(d->device));
-  sgpu_batch* b = new sgpu_batch();
+  const uint64_t nnz = q_off[nq];
+  const size_t slab = std::max<size_t>((size_t)nq * k_max, 1);
+  // *out may hold a batch to recycle (sgpu_search / sgpu_batch_search keep one per index so that a
+  // call does not pay seven hipMalloc/hipFree round trips)
+  sgpu_batch* b = *out;
+  const bool reuse = b && b->device == d->device && b->cap_nq >= nq && b->cap_nnz >= nnz && b->cap_slab >= slab;
+  if (b && !reuse) {
+    batch_free(b);
+    b = nullptr;
+    *out = nullptr;
+  }
+  if (!b) b = new sgpu_batch();
   b->device = d->device;
   b->nq = nq;
   b->k_max = k_max;
   b->max_nnz = max_nnz;
-  const uint64_t nnz = q_off[nq];
+  for (auto& pl : b->plans) (void)hipFree(pl.d_order);
+  b->plans.clear();
   b->h_off.assign(q_off, q_off + nq + 1);
   b->h_comp.assign(comps, comps + nnz);
   b->h_val.assign(vals, vals + nnz);
   std::vector<uint32_t> off32(nq + 1);
   for (uint32_t q = 0; q <= nq; ++q) off32[q] = (uint32_t)q_off[q];
-  const size_t slab = std::max<size_t>((size_t)nq * k_max, 1);
-  bool ok = hipMalloc((void**)&b->q_off, (nq + 1) * 4) == hipSuccess &&
+  bool ok = true;
+  if (!reuse) {
+    b->cap_nq = nq;
+    b->cap_nnz = nnz;
+    b->cap_slab = slab;
+    ok = hipMalloc((void**)&b->q_off, (nq + 1) * 4) == hipSuccess &&
             hipMalloc((void**)&b->q_comp, std::max<uint64_t>(nnz, 1) * 4) == hipSuccess &&
             hipMalloc((void**)&b->q_val, std::max<uint64_t>(nnz, 1) * 4) == hipSuccess &&
             hipMalloc((void**)&b->out_scores, std::max<size_t>(slab, 65536) * 4) == hipSuccess &&
             hipMalloc((void**)&b->out_ids, slab * 8) == hipSuccess &&
             hipMalloc((void**)&b->out_n, std::max<uint32_t>(nq, 1) * 4) == hipSuccess &&
             hipMalloc((void**)&b->out_stats, std::max<uint32_t>(nq, 1) * STATS_WORDS * 4) == hipSuccess;
+  }
   if (!ok) {
     batch_free(b);
+    *out = nullptr;
     return fail(SGPU_ENOMEM, "hipMalloc failed creating a query batch");
   }
   ok = hipMemcpy(b->q_off, off32.data(), (nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -346,11 +372,15 @@ sgpu_status batch_create(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, co
                      hipMemcpy(b->q_val, vals, nnz * 4, hipMemcpyHostToDevice) == hipSuccess));
   if (!ok) {
     batch_free(b);
+    *out = nullptr;
     return fail(SGPU_EDEVICE, "hipMemcpy of the query batch failed");
   }
   *out = b;
   return SGPU_OK;
 }
+
+// the recycled batch behind sgpu_search / sgpu_batch_search
+sgpu_batch** device_index_scratch_batch(DeviceIndex* d) { return d ? &d->scratch : nullptr; }
 
 static inline uint32_t up16(uint32_t x) { return (x + 15u) & ~15u; }
 

@@ -32,3 +32,8 @@ for nq in (1, 8, 64, 256, 1000):
     dt = (time.perf_counter() - t) / len(batches)
     print("nq=%4d: %.1f us wall per pass, %.1f us kernel, %.2f us/query  (env %s)" % (
         nq, dt * 1e6, km * 1e3 / len(batches), dt * 1e6 / nq, {k: v for k, v in os.environ.items() if k.startswith("SGPU_")}))
+# the host-buffer entry point (sgpu_search): H2D of the query, kernel pass, D2H of the results
+t = time.perf_counter()
+for i in range(200):
+    ix.search(qc[q_off[i]:q_off[i + 1]], qv[q_off[i]:q_off[i + 1]], 10, 4, 1.0, False)
+print("sgpu_search (host buffers in/out): %.1f us per query" % ((time.perf_counter() - t) / 200 * 1e6))
