@@ -161,3 +161,33 @@ def test_score_order_tolerance():
             b = orc.score_doc(ix.desc, doc, c, v, orc.ORDER_SEQ)
             worst = max(worst, abs(a - b) / max(1.0, abs(b)))
     assert worst <= 1e-5
+
+
+def test_oracle_knn_restatement_properties():
+    """Knn::new / Knn::refine restated (reference src/inverted_index.rs:448-500, 551-593); the
+    reference holds no known-answer test for them, so the restatement is checked for the
+    properties the source implies."""
+    dim = 200
+    off, comps, vals = random_dataset(91, 600, dim, nnz_lo=5, nnz_hi=50, empty_every=50)
+    ix = _native.NativeIndex.build(2, dim, off, comps, vals, BuildConfig.defaults(n_postings=30))
+    nknn = 5
+    nb = orc.knn_build(ix.desc, nknn)
+    assert len(nb) <= 600 * nknn and (nb < 600).all()
+    # a document is never its own neighbour wherever the lists are full-length (no misalignment yet)
+    full = len(nb) == 600 * nknn
+    if full:
+        assert (nb.reshape(600, nknn) != np.arange(600)[:, None]).all()
+    q_off, qc, qv = random_queries(92, 25, dim, 3, 30)
+    orc.knn_attach(nb, nknn)
+    try:
+        for i in range(25):
+            c, v = qc[q_off[i]:q_off[i + 1]], qv[q_off[i]:q_off[i + 1]]
+            s0, i0 = orc.search(ix.desc, c, v, 10, 2, 1.0, False)
+            s1, i1 = orc.search(ix.desc, c, v, 10, 2, 1.0, False, n_knn=nknn)
+            assert len(s1) >= len(s0)
+            assert (s1[: len(s0)] >= s0 - 0).all()              # refinement can only improve each rank
+            assert len(set(i1.tolist())) == len(i1)              # no document twice
+            for d_, s_ in zip(i1, s1):                            # every score is the true inner product
+                assert np.float32(orc.score_doc(ix.desc, int(d_), c, v)) == s_
+    finally:
+        orc.knn_attach(None, 0)
