@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "device_types.hpp"
@@ -39,6 +40,7 @@ struct DeviceIndex {
   uint32_t max_nb = 0;
   // per-launch scratch
   sgpu_batch* scratch = nullptr;   // recycled by sgpu_search / sgpu_batch_search
+  std::unordered_map<uint64_t, int> occupancy;   // kernel variant + LDS size -> workgroups per CU
   uint32_t* queue = nullptr;
   uint32_t* bitmaps = nullptr;
   uint32_t bitmaps_slots = 0;
@@ -552,8 +554,19 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   a->qb.out_n = b->out_n;
   a->qb.q_order = d_order;
   a->qb.out_stats = mode != MODE_DOTS ? b->out_stats : nullptr;
+  // occupancy of this kernel variant at this LDS size: queried once, then remembered
   int per_cu = 0;
-  HIP_TRY(occupancy_search(*a, &per_cu));
+  {
+    const uint64_t key = ((uint64_t)a->comp_width << 56) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
+                         ((uint64_t)(a->p.k <= 64 ? 1 : (a->p.k <= 128 ? 2 : 16)) << 28) | (uint64_t)(a->lds_bytes >> 4);
+    auto it = d->occupancy.find(key);
+    if (it == d->occupancy.end()) {
+      HIP_TRY(occupancy_search(*a, &per_cu));
+      d->occupancy[key] = per_cu;
+    } else {
+      per_cu = it->second;
+    }
+  }
   if (per_cu < 1) return fail(SGPU_ELIMIT, "the search kernel does not fit on a CU with %u bytes of LDS", o);
   const uint32_t cap = env_u32("SGPU_WG_PER_CU", 0);
   if (cap && (uint32_t)per_cu > cap) per_cu = (int)cap;
