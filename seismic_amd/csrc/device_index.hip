@@ -467,7 +467,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   L.dots = o; o += up16(dots_cap * 4);
   L.order = o; o += up16((sp.first_sorted && searching) ? sort_nb * 2 : 0);
   L.part = o; o += up16((NT / 64 + 1) * 4);
-  L.st = o; o += up16(136 * 4);   // state words + candidate lists (ST_WORDS)
+  L.st = o; o += up16(kStateWords * 4);   // state words + candidate lists
   // [lookup table | union region]: stage 1 uses both as one staging area (the lookup table is
   // built after stage 1); stage 2 uses the lookup table + the union region (sort keys, item tables).
   uint32_t sort_bytes = 0;
@@ -485,7 +485,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
                         !env_u32("SGPU_NO_DENSE", 0) && searching;
   const uint32_t split_bits = up16(words * 4), split_bytes = split_bits + up16(words * 2);
   // the round's item tables shrink (down to 256 items) if that is what keeps 2 workgroups per CU
-  auto uni_for = [&](uint32_t items) { return up16(std::max(items * 18 + NT * 12, sort_bytes)); };
+  auto uni_for = [&](uint32_t items) { return up16(std::max(items * 16 + NT * 12, sort_bytes)); };
   const uint32_t smallest_lookup = (d->comp_width == 4) ? split_bytes : bitmap_bytes;
   if (!std::getenv("SGPU_ITEMS_MAX")) {
     const uint32_t want = items_max;
@@ -543,6 +543,9 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   a->comp_width = d->comp_width;
   a->block = NT;
   a->lds_bytes = o;
+  if (env_u32("SGPU_DEBUG", 0))
+    std::fprintf(stderr, "sgpu configure: NT %u lookup %u items_max %u dots_cap %u uni %u lds %u\n", NT, lookup,
+                 items_max, dots_cap, uni, o);
   a->stream = d->stream;
   a->qb.q_off = b->q_off;
   a->qb.q_comp = b->q_comp;

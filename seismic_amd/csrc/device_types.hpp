@@ -46,7 +46,8 @@ struct BatchView {
 enum { MODE_SEARCH = 0, MODE_DOTS = 1, MODE_COUNTED = 2 };   // COUNTED: search with the visited bitmap (exact counters)
 // query lookup table in LDS: {32 bits, rank} per 32 ids | one byte per id | bits + 16-bit ranks
 enum { LK_PACKED = 0, LK_DENSE = 1, LK_SPLIT = 2 };
-enum { STATS_WORDS = 24 };   // per-query stats: 8 work counters + 12 phase clocks (>>4) + slot + pad
+enum { STATS_WORDS = 24 };
+enum { kStateWords = 144 };   // per-workgroup state words in LDS (ST_* in search_kernel.hip)   // per-query stats: 8 work counters + 12 phase clocks (>>4) + slot + pad
 
 struct KParams {
   uint32_t k, query_cut;

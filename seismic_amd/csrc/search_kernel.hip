@@ -144,7 +144,9 @@ struct Lds {
   uint32_t* st;         // state words
 };
 enum { ST_Q = 0, ST_NLISTS = 1, ST_THR = 2, ST_HLEN = 3, ST_TMP0 = 4, ST_TMP1 = 5, ST_TMP2 = 6, ST_NCAND = 7,
-       ST_CAND = 8 /* 64 candidate item indices */, ST_CAND_SORTED = 72 /* 64 */, ST_WORDS = 136 };
+       ST_CAND = 8 /* 64 candidate item indices */, ST_CAND_SORTED = 72 /* 64 */, ST_NSHORT = 136, ST_NLONG = 137,
+       ST_PULL_L = 138 };
+static_assert(ST_PULL_L < kStateWords, "state words");
 constexpr uint32_t kMaxCand = 64;
 
 SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
@@ -532,8 +534,8 @@ struct ChunkBufs {   // carved from the union region
   uint16_t* cb_blk;     // [NT] block id (list-local)
   uint64_t* it_ref;     // [ITEMS] packed doc record ref; high 32 bits reused for the score
   uint32_t* it_doc;     // [ITEMS] doc id | (already visited) << 31
-  uint16_t* it_blk;     // [ITEMS]
-  float* it_dot;        // [ITEMS] summary dot of the item's block
+  uint16_t* it_blk;     // [ITEMS] list-local block id (its summary dot is dots[it_blk])
+  uint16_t* it_ord;     // [ITEMS] item indices by length class: <= 128 elements from the front, longer from the back
 };
 
 template <int NT>
@@ -542,10 +544,10 @@ SGPU_DEV ChunkBufs carve_chunk(uint8_t* uni, uint32_t items_max) {
   uint8_t* p = uni;
   c.it_ref = (uint64_t*)p;  p += (size_t)items_max * 8;
   c.it_doc = (uint32_t*)p;  p += (size_t)items_max * 4;
-  c.it_dot = (float*)p;     p += (size_t)items_max * 4;
   c.cb_incl = (uint32_t*)p; p += NT * 4;
   c.cb_p0 = (uint32_t*)p;   p += NT * 4;
   c.it_blk = (uint16_t*)p;  p += (size_t)items_max * 2;
+  c.it_ord = (uint16_t*)p;  p += (size_t)items_max * 2;
   c.live_pos = (uint16_t*)p; p += NT * 2;
   c.cb_blk = (uint16_t*)p;
   return c;
@@ -599,10 +601,20 @@ SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0
     // one byte per vocabulary id: 1 + rank in the query, 0 = absent (-> q_val[-1] == 0.0).
     // Padding components carry the sentinel id `dim`, whose byte is always 0: no length test.
     uint32_t r[8];
+#if defined(SGPU_EXP) && SGPU_EXP == 1   // experiment: no lookups at all
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = __uint_as_float(c[i]);
+#elif defined(SGPU_EXP) && SGPU_EXP == 2   // experiment: first lookup only
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = s.q_idx[c[i]];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qv[i] = __uint_as_float(r[i]);
+#else
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = s.q_idx[c[i]];
 #pragma unroll
     for (int i = 0; i < 8; ++i) qv[i] = s.q_val[(int)r[i] - 1];
+#endif
   } else {
     uint2 w[8];
 #pragma unroll
@@ -685,7 +697,9 @@ SGPU_DEV bool heap_contains(const RegHeap<KR>& heap, uint32_t d) {
 template <int KR, bool USE_BITMAP>
 SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_items, uint32_t k,
                            float heap_factor, uint32_t* bitmap, uint32_t& decided_blk,
-                           bool block_starts_at_0, WorkCount& wc, uint32_t& live_items, bool dups) {
+                           bool block_starts_at_0, WorkCount& wc, uint32_t& live_items, bool dups,
+                           const float* dots) {
+  // dots: summary dots of the current list (LDS); nullptr = no block test (kNN refinement)
   // dups: the round may hold the same document more than once (kNN refinement: two results can
   // share a neighbour; a posting list never repeats a document). The reference inserts into its
   // visited set item by item, so a later copy must see the earlier one.
@@ -700,7 +714,7 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_it
       // cannot change the heap; without a visited set to maintain there is nothing else to do.
       // (Work counters are exact only in the counted pass, which never takes this shortcut.)
       const float sc0 = valid ? __uint_as_float(it_words[2 * idx + 1]) : 0.0f;
-      const float bd0 = valid ? cb.it_dot[idx] : 0.0f;
+      const float bd0 = valid ? (dots ? dots[cb.it_blk[idx]] : __builtin_inff()) : 0.0f;
       if (__ballot(valid && sc0 > heap.thr) == 0ull) {
         live_items += (uint32_t)__popcll(__ballot(valid && !(bd0 < __fmul_rn(heap_factor, heap.thr))));
         i += 64;
@@ -712,13 +726,13 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_it
     float bdot = 0.0f;
     bool vis = true, first = false;
     if (valid) {
-      bdot = cb.it_dot[idx];
       sc = __uint_as_float(it_words[2 * idx + 1]);
       len = it_words[2 * idx] & 0xffffu;
       const uint32_t d = cb.it_doc[idx];
       doc = d & 0x7fffffffu;
       vis = (d >> 31) != 0;
       blk = cb.it_blk[idx];
+      bdot = dots ? dots[blk] : __builtin_inff();
       first = idx == 0 ? block_starts_at_0 : (cb.it_blk[idx - 1] != blk);
     }
     if (dups && USE_BITMAP) {   // marks made earlier in this round (by this wavefront) must be seen
@@ -807,7 +821,7 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_it
 // replay_chunk, everything in registers.
 template <int KR>
 SGPU_DEV void replay_candidates(RegHeap<KR>& heap, const ChunkBufs& cb, const uint32_t* st, uint32_t nc,
-                                uint32_t k, float heap_factor, uint32_t& decided_blk) {
+                                uint32_t k, float heap_factor, uint32_t& decided_blk, const float* dots) {
   const uint32_t lane = lane_id();
   const uint32_t* it_words = (const uint32_t*)cb.it_ref;
   uint32_t idx = lane < nc ? st[ST_CAND + lane] : 0xffffffffu;
@@ -821,9 +835,9 @@ SGPU_DEV void replay_candidates(RegHeap<KR>& heap, const ChunkBufs& cb, const ui
   uint32_t doc = 0, blk = 0;
   if (lane < nc) {
     sc = __uint_as_float(it_words[2 * idx + 1]);
-    bdot = cb.it_dot[idx];
     doc = cb.it_doc[idx] & 0x7fffffffu;
     blk = cb.it_blk[idx];
+    bdot = dots ? dots[blk] : __builtin_inff();
   }
   for (uint32_t c = 0; c < nc; ++c) {
     const float sc_c = readlane_f(sc, c);
@@ -839,94 +853,135 @@ SGPU_DEV void replay_candidates(RegHeap<KR>& heap, const ChunkBufs& cb, const ui
   }
 }
 
-// Phase B: speculative scoring of the round's items, 16 lanes per document. Groups pull documents
-// two at a time from a shared counter (documents differ 25x in length) and fetch the first TWO
-// 128-element slices of each document up front (a third of the documents need the second).
-// When the heap is already full (and no visited bitmap is kept) the items scoring above the
-// round's starting threshold are collected for replay_candidates.
-template <typename CT, int NT, int LK>
-SGPU_DEV void score_items(const Lds& s, const DevView& ix, const ChunkBufs& cb, const KParams& p,
-                          uint32_t n_items, uint32_t& spec_docs) {
+// Phase B: speculative scoring of the round's items, 16 lanes per document. Phase A sorted the
+// items into two classes by length (ChunkBufs::it_ord): documents of at most 128 elements (one
+// slice of 8 elements per lane; two thirds of a SPLADE-shaped collection) are scored FOUR at a time
+// per lane group, longer ones two at a time with their first two slices fetched up front. Either
+// way a lane group keeps 4 slices (128 B per lane) in flight, which is what the register budget of
+// 2 x 512 threads per CU allows; the short class just has no half-empty second slices among them.
+// Groups pull documents from a shared counter (a step ahead of their use). When the heap is
+// already full (and no visited bitmap is kept) the items scoring above the round's starting
+// threshold are collected for replay_candidates.
+template <typename CT, int LK, int ND, int NS>
+SGPU_DEV void score_class(const Lds& s, const DevView& ix, const ChunkBufs& cb, const uint16_t* list, int dir,
+                          uint32_t n, uint32_t* pull, bool collect, float thr0, uint32_t& spec_docs) {
   const uint32_t sub = threadIdx.x & 15;
   float* it_score = (float*)cb.it_ref;
   const uint32_t e0 = sub * 8u;
-  const bool collect = !p.use_bitmap && s.st[ST_HLEN] == p.k;   // heap full: only scores above the
-  const float thr0 = __uint_as_float(s.st[ST_THR]);            // current k-th best can matter
   uint32_t i_next = 0;
-  if (sub == 0) i_next = atomicAdd(&s.st[ST_TMP2], 2u);
+  if (sub == 0) i_next = atomicAdd(pull, (uint32_t)ND);
   for (;;) {
     const uint32_t i = row_bcast0(i_next);
-    if (i >= n_items) break;
+    if (i >= n) break;
     // the pull for the following step is issued before this step's work
-    if (sub == 0) i_next = atomicAdd(&s.st[ST_TMP2], 2u);
-    uint32_t len[2];
-    const uint8_t* rec[2];
-    const uint8_t* val[2];
-    DocChunk<CT> d[2][2];
+    if (sub == 0) i_next = atomicAdd(pull, (uint32_t)ND);
+    uint32_t len[ND], item[ND];
+    const uint8_t* rec[ND];
+    const uint8_t* val[ND];
+    DocChunk<CT> d[ND][NS];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < ND; ++u) {
       const uint32_t iu = i + (uint32_t)u;
-      const bool has = iu < n_items;
-      const uint64_t ref = has ? cb.it_ref[iu] : 0ull;
-      const bool run = has && (cb.it_doc[has ? iu : 0] >> 31) == 0;
-      len[u] = run ? (uint32_t)(ref & 0xffffu) : 0u;
+      const bool has = iu < n;
+      item[u] = has ? (uint32_t)list[(int)iu * dir] : 0xffffffffu;
+      const uint64_t ref = has ? cb.it_ref[item[u]] : 0ull;
+      len[u] = (uint32_t)(ref & 0xffffu);
       rec[u] = ix.fwd + (ref >> 16) * 16ull;
       val[u] = rec[u] + (size_t)((len[u] + 7u) & ~7u) * sizeof(CT);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < ND; ++u) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NS; ++h) {
         d[u][h].c0 = d[u][h].c1 = d[u][h].v = make_uint4(0, 0, 0, 0);
         if (e0 + 128u * h < len[u]) load_chunk<CT>(d[u][h], rec[u], val[u], e0 + 128u * h);
       }
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < ND; ++u) {
       float a = 0.0f;
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+      for (int h = 0; h < NS; ++h)
         if (e0 + 128u * h < len[u]) a = accumulate_chunk<CT, LK>(s, d[u][h], e0 + 128u * h, len[u], a);
-      for (uint32_t e = e0 + 256u; e < len[u]; e += 128u) {   // documents longer than 256
-        load_chunk<CT>(d[u][0], rec[u], val[u], e);
-        a = accumulate_chunk<CT, LK>(s, d[u][0], e, len[u], a);
+      if (NS > 1) {
+        for (uint32_t e = e0 + 128u * NS; e < len[u]; e += 128u) {   // documents longer than 256
+          load_chunk<CT>(d[u][0], rec[u], val[u], e);
+          a = accumulate_chunk<CT, LK>(s, d[u][0], e, len[u], a);
+        }
       }
       a = reduce16(a);
-      const uint32_t iu = i + (uint32_t)u;
       spec_docs += (sub == 0 && len[u] != 0);
-      if (sub == 0 && iu < n_items) {
-        it_score[2 * iu + 1] = a;
+      if (sub == 0 && item[u] != 0xffffffffu) {
+        it_score[2 * item[u] + 1] = a;
         if (collect && len[u] != 0 && a > thr0) {
           const uint32_t slot = atomicAdd(&s.st[ST_NCAND], 1u);
-          if (slot < kMaxCand) s.st[ST_CAND + slot] = iu;
+          if (slot < kMaxCand) s.st[ST_CAND + slot] = item[u];
         }
       }
     }
   }
 }
 
+#ifndef SGPU_ND_SHORT
+#define SGPU_ND_SHORT 4
+#endif
+#ifndef SGPU_ND_LONG
+#define SGPU_ND_LONG 2
+#endif
+template <typename CT, int NT, int LK>
+SGPU_DEV void score_items(const Lds& s, const DevView& ix, const ChunkBufs& cb, const KParams& p,
+                          uint32_t& spec_docs) {
+  const bool collect = !p.use_bitmap && s.st[ST_HLEN] == p.k;   // heap full: only scores above the
+  const float thr0 = __uint_as_float(s.st[ST_THR]);            // current k-th best can matter
+  const uint32_t n_short = s.st[ST_NSHORT], n_long = s.st[ST_NLONG];
+  score_class<CT, LK, SGPU_ND_SHORT, 1>(s, ix, cb, cb.it_ord, 1, n_short, &s.st[ST_TMP2], collect, thr0, spec_docs);
+  score_class<CT, LK, SGPU_ND_LONG, 2>(s, ix, cb, cb.it_ord + (p.items_max - 1), -1, n_long, &s.st[ST_PULL_L], collect, thr0,
+                            spec_docs);
+}
+
+// Phase A's last step: file item i under its length class (wave-aggregated list appends). Items the
+// counted pass already knows as visited are not scored at all.
+SGPU_DEV void classify_item(uint32_t* st, const ChunkBufs& cb, uint32_t items_max, uint32_t i, uint32_t len,
+                            bool take) {
+  const bool sh = take && len <= 128u, lg = take && len > 128u;
+  const uint64_t ms = __ballot(sh), ml = __ballot(lg);
+  const uint32_t lane = lane_id();
+  uint32_t bs = 0, bl = 0;
+  if (lane == 0) {
+    if (ms) bs = atomicAdd(&st[ST_NSHORT], (uint32_t)__popcll(ms));
+    if (ml) bl = atomicAdd(&st[ST_NLONG], (uint32_t)__popcll(ml));
+  }
+  bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs);
+  bl = (uint32_t)__builtin_amdgcn_readfirstlane((int)bl);
+  const uint64_t below = (1ull << lane) - 1ull;
+  if (sh) cb.it_ord[bs + (uint32_t)__popcll(ms & below)] = (uint16_t)i;
+  if (lg) cb.it_ord[items_max - 1u - (bl + (uint32_t)__popcll(ml & below))] = (uint16_t)i;
+}
+
 // Replay of one round on wavefront 0 + publication of the new heap state for the next filter.
 template <int KR>
 SGPU_DEV void replay_round(RegHeap<KR>& heap, const ChunkBufs& cb, const Lds& s, const KParams& p,
                            uint32_t n_items, uint32_t* bitmap, uint32_t& decided_blk, bool block_starts_at_0,
-                           WorkCount& wc, bool dups = false) {
+                           WorkCount& wc, const float* dots, bool dups = false) {
   uint32_t live_items = 0;
   const uint32_t nc = s.st[ST_NCAND];
   if (!p.use_bitmap && heap.len == p.k && nc <= kMaxCand) {
     // (the heap was full when the round started: phase B collected every item that can matter)
-    replay_candidates<KR>(heap, cb, s.st, nc, p.k, p.heap_factor, decided_blk);
+    replay_candidates<KR>(heap, cb, s.st, nc, p.k, p.heap_factor, decided_blk, dots);
     live_items = n_items;
   } else if (p.use_bitmap) {
     replay_chunk<KR, true>(heap, cb, n_items, p.k, p.heap_factor, bitmap, decided_blk, block_starts_at_0, wc,
-                           live_items, dups);
+                           live_items, dups, dots);
   } else {
     replay_chunk<KR, false>(heap, cb, n_items, p.k, p.heap_factor, bitmap, decided_blk, block_starts_at_0, wc,
-                            live_items, dups);
+                            live_items, dups, dots);
   }
   if (lane_id() == 0) {
     s.st[ST_HLEN] = heap.len;
     s.st[ST_THR] = __float_as_uint(heap.len == p.k ? heap.thr : 0.0f);
     s.st[ST_TMP1] = live_items;
+    s.st[ST_NSHORT] = 0;   // the next round's class lists start empty
+    s.st[ST_NLONG] = 0;
   }
 }
 
@@ -984,6 +1039,8 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
     if (threadIdx.x == 0) {
       s.st[ST_HLEN] = 0;
       s.st[ST_THR] = 0;
+      s.st[ST_NSHORT] = 0;
+      s.st[ST_NLONG] = 0;
     }
     __syncthreads();
     if (p.mode == MODE_DOTS) {   // sgpu_summary_distances: aim stage 1 at one given list
@@ -1124,10 +1181,16 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             piece_items = n_items;
             // (c) phase A: posting refs (thread per item; + visited bits in the counted pass)
             if (threadIdx.x == 0) {
-              s.st[ST_TMP2] = 0;    // phase B's item counter
+              s.st[ST_TMP2] = 0;    // phase B's item counters
+              s.st[ST_PULL_L] = 0;
               s.st[ST_NCAND] = 0;   // phase B's candidate counter
             }
-            for (uint32_t i = threadIdx.x; i < n_items; i += NT) {
+            for (uint32_t ib = 0; ib < n_items; ib += NT) {
+              const uint32_t i = ib + threadIdx.x;
+              if (i >= n_items) {
+                classify_item(s.st, cb, p.items_max, 0, 0, false);
+                continue;
+              }
               const uint32_t gi = i + item0;
               uint32_t lo = 0, hi = nblk;   // first block with cb_incl > gi
               while (lo < hi) {
@@ -1141,18 +1204,17 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
               const uint32_t vis = (p.use_bitmap && visited_test(bitmap, doc)) ? 0x80000000u : 0u;
               cb.it_ref[i] = ref;
               cb.it_doc[i] = doc | vis;
-              const uint32_t blk = cb.cb_blk[lo];
-              cb.it_blk[i] = (uint16_t)blk;
-              cb.it_dot[i] = dots[blk];
+              cb.it_blk[i] = (uint16_t)cb.cb_blk[lo];
+              classify_item(s.st, cb, p.items_max, i, (uint32_t)(ref & 0xffffu), vis == 0);
             }
             __syncthreads();
             TICK(6);
             // (d) phase B: speculative scoring (score_items)
-            score_items<CT, NT, LK>(s, ix, cb, p, n_items, spec_docs);
+            score_items<CT, NT, LK>(s, ix, cb, p, spec_docs);
             __syncthreads();
             TICK(7);
             // (e) exact replay on wavefront 0
-            if (wave == 0) replay_round<KR>(heap, cb, s, p, n_items, bitmap, decided_blk, piece == 0, wc);
+            if (wave == 0) replay_round<KR>(heap, cb, s, p, n_items, bitmap, decided_blk, piece == 0, wc, dots);
             __syncthreads();
             TICK(8);
           }
@@ -1189,9 +1251,15 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
           const uint32_t n_items = total - base < p.items_max ? total - base : p.items_max;
           if (threadIdx.x == 0) {
             s.st[ST_TMP2] = 0;
+            s.st[ST_PULL_L] = 0;
             s.st[ST_NCAND] = 0;
           }
-          for (uint32_t i = threadIdx.x; i < n_items; i += NT) {
+          for (uint32_t ib = 0; ib < n_items; ib += NT) {
+            const uint32_t i = ib + threadIdx.x;
+            if (i >= n_items) {
+              classify_item(s.st, cb, p.items_max, 0, 0, false);
+              continue;
+            }
             const uint32_t j = base + i;
             const uint32_t r = j / nk, t = j - r * nk;
             const uint64_t pos = (uint64_t)snap[r] * ix.knn_dim + t;
@@ -1202,13 +1270,13 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             const bool vis = !ok || (p.use_bitmap && visited_test(bitmap, nbr));
             cb.it_ref[i] = ref;
             cb.it_doc[i] = nbr | (vis ? 0x80000000u : 0u);
-            cb.it_blk[i] = 0;
-            cb.it_dot[i] = __builtin_inff();   // no block test in the refinement
+            cb.it_blk[i] = 0;   // no block test in the refinement (replay gets dots == nullptr)
+            classify_item(s.st, cb, p.items_max, i, (uint32_t)(ref & 0xffffu), !vis);
           }
           __syncthreads();
-          score_items<CT, NT, LK>(s, ix, cb, p, n_items, spec_docs);
+          score_items<CT, NT, LK>(s, ix, cb, p, spec_docs);
           __syncthreads();
-          if (wave == 0) replay_round<KR>(heap, cb, s, p, n_items, bitmap, decided_blk, true, wc, true);
+          if (wave == 0) replay_round<KR>(heap, cb, s, p, n_items, bitmap, decided_blk, true, wc, nullptr, true);
           __syncthreads();
         }
       }
