@@ -466,7 +466,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   L.rt_pre = o; o += up16(qc * (qn + 1) * 4);
   L.dots = o; o += up16(dots_cap * 4);
   L.order = o; o += up16((sp.first_sorted && searching) ? sort_nb * 2 : 0);
-  L.part = o; o += up16((NT / 64 + 1) * 4);
+  L.part = o; o += up16(2 * (NT / 64 + 1) * 4);   // two scan scratch areas, used alternately
   L.st = o; o += up16(kStateWords * 4);   // state words + candidate lists
   // [lookup table | union region]: stage 1 uses both as one staging area (the lookup table is
   // built after stage 1); stage 2 uses the lookup table + the union region (sort keys, item tables).

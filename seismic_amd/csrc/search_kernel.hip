@@ -95,16 +95,25 @@ SGPU_DEV float shift_up1_f(float v) { return __uint_as_float(shift_up1_u(__float
 
 // inclusive scan of one u32 per thread over the whole workgroup.
 // `part` points to NT/64 + 1 LDS words. Returns inclusive prefix; *total = sum.
+// Inclusive prefix sum over the 64 lanes: four row shifts inside each row of 16, then the row
+// totals carried with row_bcast:15 / row_bcast:31 (lanes without a source add 0).
+#define SGPU_DPP0(x, ctrl, rows) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(x), ctrl, rows, 0xf, false))
+SGPU_DEV uint32_t wave_inclusive_scan(uint32_t x) {
+  x += SGPU_DPP0(x, 0x111, 0xf);   // row_shr:1
+  x += SGPU_DPP0(x, 0x112, 0xf);   // row_shr:2
+  x += SGPU_DPP0(x, 0x114, 0xf);   // row_shr:4
+  x += SGPU_DPP0(x, 0x118, 0xf);   // row_shr:8
+  x += SGPU_DPP0(x, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+  x += SGPU_DPP0(x, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+
+// One barrier: the caller guarantees that every thread is past its reads of `part` from the previous
+// scan that used it (another barrier lies in between).
 template <int NT>
 SGPU_DEV uint32_t wg_inclusive_scan(uint32_t v, uint32_t* part, uint32_t* total) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t y = __shfl_up(x, d);
-    if (lane >= (uint32_t)d) x += y;
-  }
-  __syncthreads();  // protect `part` from the previous use
+  const uint32_t x = wave_inclusive_scan(v);
   if (lane == 63) part[wave] = x;
   __syncthreads();
   uint32_t base = 0, tot = 0;
@@ -145,8 +154,8 @@ struct Lds {
 };
 enum { ST_Q = 0, ST_NLISTS = 1, ST_THR = 2, ST_HLEN = 3, ST_TMP0 = 4, ST_TMP1 = 5, ST_TMP2 = 6, ST_NCAND = 7,
        ST_CAND = 8 /* 64 candidate item indices */, ST_CAND_SORTED = 72 /* 64 */, ST_NSHORT = 136, ST_NLONG = 137,
-       ST_PULL_L = 138 };
-static_assert(ST_PULL_L < kStateWords, "state words");
+       ST_PULL_L = 138, ST_NBLK = 139 };
+static_assert(ST_NBLK < kStateWords, "state words");
 constexpr uint32_t kMaxCand = 64;
 
 SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
@@ -781,36 +790,44 @@ SGPU_DEV void replay_chunk(RegHeap<KR>& heap, const ChunkBufs& cb, uint32_t n_it
       i += last + 1;
       continue;
     }
-    const float thr = heap.thr;
-    const float cut = __fmul_rn(heap_factor, thr);
-    const bool live = valid && ((blk == decided_blk) || !(bdot < cut));
-    const bool changing = live && !vis && (sc > thr);
-    uint64_t cm = __ballot(changing);
-    if (!USE_BITMAP) {   // drop recurring documents: they are in the heap already
-      while (cm) {
-        const uint32_t c0 = (uint32_t)(__ffsll((long long)cm) - 1);
-        if (!heap_contains<KR>(heap, readlane_u(doc, c0))) break;
-        cm &= cm - 1;
+    // Heap full: the window's 64 items stay in registers; every heap change re-evaluates the
+    // remaining lanes against the new threshold (the reference's per-item test, 64 at a time).
+    uint32_t start = 0, advance = 64;
+    for (;;) {
+      const float thr = heap.thr;
+      const float cut = __fmul_rn(heap_factor, thr);
+      const bool live = valid && lane >= start && ((blk == decided_blk) || !(bdot < cut));
+      const bool changing = live && !vis && (sc > thr);
+      uint64_t cm = __ballot(changing);
+      if (!USE_BITMAP) {   // drop recurring documents: they are in the heap already
+        while (cm) {
+          const uint32_t c0 = (uint32_t)(__ffsll((long long)cm) - 1);
+          if (!heap_contains<KR>(heap, readlane_u(doc, c0))) break;
+          cm &= cm - 1;
+        }
       }
-    }
-    const uint32_t f = cm ? (uint32_t)(__ffsll((long long)cm) - 1) : 63u;
-    live_items += (uint32_t)__popcll(__ballot(live && lane <= f));
-    if (live && lane <= f) {
-      wc.posts += 1;
-      wc.blocks += first;
-      if (!vis) {
-        if (USE_BITMAP) visited_mark(bitmap, doc);
-        wc.docs += 1;   // without the bitmap this also counts recurring documents that were rejected
-        wc.len += len;
+      const uint32_t f = cm ? (uint32_t)(__ffsll((long long)cm) - 1) : 63u;
+      live_items += (uint32_t)__popcll(__ballot(live && lane <= f));
+      if (USE_BITMAP && live && lane <= f) {   // exact work counters: the counted pass only
+        wc.posts += 1;
+        wc.blocks += first;
+        if (!vis) {
+          visited_mark(bitmap, doc);
+          wc.docs += 1;
+          wc.len += len;
+        }
       }
+      if (cm == 0) break;
+      heap.insert(readlane_f(sc, f), readlane_u(doc, f), k);
+      decided_blk = readlane_u(blk, f);
+      if (dups) {   // later copies of a document must see this step's visited marks: reload the window
+        advance = f + 1;
+        break;
+      }
+      start = f + 1;
+      if (start >= 64) break;
     }
-    if (cm == 0) {
-      i += 64;
-      continue;
-    }
-    heap.insert(readlane_f(sc, f), readlane_u(doc, f), k);
-    decided_blk = readlane_u(blk, f);
-    i += f + 1;
+    i += advance;
   }
 }
 
@@ -839,16 +856,21 @@ SGPU_DEV void replay_candidates(RegHeap<KR>& heap, const ChunkBufs& cb, const ui
     blk = cb.it_blk[idx];
     bdot = dots ? dots[blk] : __builtin_inff();
   }
-  for (uint32_t c = 0; c < nc; ++c) {
-    const float sc_c = readlane_f(sc, c);
+  // lane c holds the c-th candidate in item order; each step jumps to the next one that still beats
+  // the (rising) threshold, so the loop runs once per heap change rather than once per candidate
+  uint64_t todo = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);
+  for (;;) {
     const float thr = heap.thr;
-    if (!(sc_c > thr)) continue;
+    todo &= __ballot(sc > thr);
+    if (todo == 0) break;
+    const uint32_t c = (uint32_t)(__ffsll((long long)todo) - 1);
+    todo &= todo - 1;
     const uint32_t blk_c = readlane_u(blk, c);
     const bool live = (blk_c == decided_blk) || !(readlane_f(bdot, c) < __fmul_rn(heap_factor, thr));
     if (!live) continue;
     const uint32_t doc_c = readlane_u(doc, c);
     if (heap_contains<KR>(heap, doc_c)) continue;   // re-encountered document: already in the heap
-    heap.insert(sc_c, doc_c, k);
+    heap.insert(readlane_f(sc, c), doc_c, k);
     decided_blk = blk_c;
   }
 }
@@ -933,7 +955,7 @@ SGPU_DEV void score_items(const Lds& s, const DevView& ix, const ChunkBufs& cb, 
                           uint32_t& spec_docs) {
   const bool collect = !p.use_bitmap && s.st[ST_HLEN] == p.k;   // heap full: only scores above the
   const float thr0 = __uint_as_float(s.st[ST_THR]);            // current k-th best can matter
-  const uint32_t n_short = s.st[ST_NSHORT], n_long = s.st[ST_NLONG];
+  const uint32_t n_short = s.st[ST_NSHORT] & 0xffffu, n_long = s.st[ST_NSHORT] >> 16;
   score_class<CT, LK, SGPU_ND_SHORT, 1>(s, ix, cb, cb.it_ord, 1, n_short, &s.st[ST_TMP2], collect, thr0, spec_docs);
   score_class<CT, LK, SGPU_ND_LONG, 2>(s, ix, cb, cb.it_ord + (p.items_max - 1), -1, n_long, &s.st[ST_PULL_L], collect, thr0,
                             spec_docs);
@@ -946,13 +968,10 @@ SGPU_DEV void classify_item(uint32_t* st, const ChunkBufs& cb, uint32_t items_ma
   const bool sh = take && len <= 128u, lg = take && len > 128u;
   const uint64_t ms = __ballot(sh), ml = __ballot(lg);
   const uint32_t lane = lane_id();
-  uint32_t bs = 0, bl = 0;
-  if (lane == 0) {
-    if (ms) bs = atomicAdd(&st[ST_NSHORT], (uint32_t)__popcll(ms));
-    if (ml) bl = atomicAdd(&st[ST_NLONG], (uint32_t)__popcll(ml));
-  }
-  bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs);
-  bl = (uint32_t)__builtin_amdgcn_readfirstlane((int)bl);
+  uint32_t both = 0;   // both list lengths live in one word: short | long << 16
+  if (lane == 0 && (ms | ml)) both = atomicAdd(&st[ST_NSHORT], (uint32_t)__popcll(ms) | ((uint32_t)__popcll(ml) << 16));
+  both = (uint32_t)__builtin_amdgcn_readfirstlane((int)both);
+  const uint32_t bs = both & 0xffffu, bl = both >> 16;
   const uint64_t below = (1ull << lane) - 1ull;
   if (sh) cb.it_ord[bs + (uint32_t)__popcll(ms & below)] = (uint16_t)i;
   if (lg) cb.it_ord[items_max - 1u - (bl + (uint32_t)__popcll(ml & below))] = (uint16_t)i;
@@ -981,7 +1000,6 @@ SGPU_DEV void replay_round(RegHeap<KR>& heap, const ChunkBufs& cb, const Lds& s,
     s.st[ST_THR] = __float_as_uint(heap.len == p.k ? heap.thr : 0.0f);
     s.st[ST_TMP1] = live_items;
     s.st[ST_NSHORT] = 0;   // the next round's class lists start empty
-    s.st[ST_NLONG] = 0;
   }
 }
 
@@ -1036,11 +1054,13 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
     heap.reset();
     wc = WorkCount{0, 0, 0, 0};
     uint32_t spec_docs = 0, st_entries = 0, st_rows = 0;
+#ifdef SGPU_PROF_REPLAY
+    uint32_t xr_cand = 0, xr_full = 0, xr_nfull = 0;
+#endif
     if (threadIdx.x == 0) {
       s.st[ST_HLEN] = 0;
       s.st[ST_THR] = 0;
       s.st[ST_NSHORT] = 0;
-      s.st[ST_NLONG] = 0;
     }
     __syncthreads();
     if (p.mode == MODE_DOTS) {   // sgpu_summary_distances: aim stage 1 at one given list
@@ -1115,6 +1135,7 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
           const uint32_t live_incl = wg_inclusive_scan<NT>(my_live, s.part, &n_live_total);
           if (n_live_total == 0) {
             pos = scan_end;
+            __syncthreads();   // everyone is done with s.part before the next scan writes it
             TICK(4);
             continue;
           }
@@ -1140,23 +1161,27 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             cnt = ix.block_post_start[b0 + myb + 1] - p0;
           }
           uint32_t items_total;
-          const uint32_t incl = wg_inclusive_scan<NT>(cnt, s.part, &items_total);
-          if (threadIdx.x == 0) s.st[ST_TMP0] = cnt;   // size of the first live block
-          __syncthreads();
+          if (threadIdx.x == 0) {
+            s.st[ST_TMP0] = cnt;   // size of the first live block
+            s.st[ST_NBLK] = 0;
+          }
+          const uint32_t incl = wg_inclusive_scan<NT>(cnt, s.part + (NT / 64 + 1), &items_total);
           const uint32_t first_cnt = s.st[ST_TMP0];
           uint32_t B = budget;
           if (first_cnt > B) B = first_cnt;             // always make progress
           const bool oversize = first_cnt > p.items_max;
           if (B > p.items_max) B = p.items_max;
-          uint32_t taken = (threadIdx.x < n_live && incl <= B) ? 1u : 0u;
-          uint32_t nblk;
-          (void)wg_inclusive_scan<NT>(taken, s.part, &nblk);
+          {   // blocks taken this round: the live blocks whose inclusive item count fits the budget
+            const uint64_t tk = __ballot(threadIdx.x < n_live && incl <= B);
+            if (lane == 0 && tk) atomicAdd(&s.st[ST_NBLK], (uint32_t)__popcll(tk));
+          }
           if (threadIdx.x < n_live) {
             cb.cb_incl[threadIdx.x] = incl;
             cb.cb_p0[threadIdx.x] = p0;
             cb.cb_blk[threadIdx.x] = (uint16_t)myb;
           }
           __syncthreads();
+          uint32_t nblk = s.st[ST_NBLK];
           uint32_t next_pos;
           uint32_t n_pieces = 1, piece_items = 0;
           if (oversize) {   // one block larger than the item buffer: evaluate it in pieces
@@ -1214,9 +1239,22 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             __syncthreads();
             TICK(7);
             // (e) exact replay on wavefront 0
+#ifdef SGPU_PROF_REPLAY
+            {
+              const uint32_t nc_ = s.st[ST_NCAND];
+              const bool cand_ = s.st[ST_HLEN] == p.k && nc_ <= kMaxCand;
+              const uint64_t t0_ = clock64();
+              if (wave == 0) replay_round<KR>(heap, cb, s, p, n_items, bitmap, decided_blk, piece == 0, wc, dots);
+              const uint32_t dt_ = (uint32_t)((clock64() - t0_) >> 4);
+              if (cand_) { xr_cand += dt_; } else { xr_full += dt_; xr_nfull += 1; }
+              __syncthreads();
+              TICK(8);
+            }
+#else
             if (wave == 0) replay_round<KR>(heap, cb, s, p, n_items, bitmap, decided_blk, piece == 0, wc, dots);
             __syncthreads();
             TICK(8);
+#endif
           }
           pos = next_pos;
           // adapt the speculation budget to how much of the last round the replay kept
@@ -1332,6 +1370,9 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
 #pragma unroll
       for (int i = 0; i < 12; ++i) os[i] = prof[i];
       os[12] = blockIdx.x;
+#ifdef SGPU_PROF_REPLAY
+      os[13] = xr_cand; os[14] = xr_full; os[15] = xr_nfull;
+#endif
     }
 #undef TICK
   }
