@@ -468,8 +468,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   L.order = o; o += up16((sp.first_sorted && searching) ? sort_nb * 2 : 0);
   L.part = o; o += up16(2 * (NT / 64 + 1) * 4);   // two scan scratch areas, used alternately
   L.st = o; o += up16(kStateWords * 4);   // state words + candidate lists
-  // [lookup table | union region]: stage 1 uses both as one staging area (the lookup table is
-  // built after stage 1); stage 2 uses the lookup table + the union region (sort keys, item tables).
+  // [lookup table | union region (sort keys, item tables)]
   uint32_t sort_bytes = 0;
   if (sp.first_sorted && searching && sort_nb > 1) {
     uint32_t n2 = 1;
@@ -509,17 +508,11 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   L.q_rank = o + (split ? split_bits : lookup_bytes);
   o += lookup_bytes;
   L.uni = o;
-  uint32_t uni = min_uni;
-  const uint32_t min_stage = qc * 64u * 6u + 16u;
-  if (lookup_bytes + uni < min_stage) uni = up16(min_stage - lookup_bytes);
-  uint32_t stage_bytes = env_u32("SGPU_STAGE_BYTES", 0);
-  if (stage_bytes) uni = std::max(uni, up16(stage_bytes > lookup_bytes ? stage_bytes - lookup_bytes : 0u));
-  else if (o + uni < budget) uni = (budget - o) & ~15u;   // give stage 1 whatever is left at this occupancy
+  const uint32_t uni = min_uni;
   o += uni;
   L.qc = qc;
   L.qn = qn;
   a->lookup = lookup;
-  a->p.stage_cap = (lookup_bytes + uni) / 6;
   L.total = o;
   if (o > lds_limit)
     return fail(SGPU_ELIMIT,

@@ -54,7 +54,6 @@ struct KParams {
   float heap_factor;
   int32_t first_sorted;
   uint32_t mode;
-  uint32_t stage_cap;    // staging entries (8 B each) available in the union region
   uint32_t items_max;    // speculative documents per round (LDS item table)
   uint32_t items_init;   // first round's budget; adapts to the replay's keep ratio
   uint32_t items_min;    // lower bound of the budget

@@ -147,15 +147,15 @@ struct Lds {
   uint32_t* rt_pre;     // [QC*(QN+1)] flattened prefix of matched row lengths
   float* dots;
   uint16_t* order;
-  uint8_t* stage;       // stage-1 staging: from the lookup table region to the end of the union region
+  uint8_t* lookup;      // start of the query lookup table (whichever layout)
   uint8_t* uni;         // union region
   uint32_t* part;       // scan partials [NT/64 + 1]
   uint32_t* st;         // state words
 };
 enum { ST_Q = 0, ST_NLISTS = 1, ST_THR = 2, ST_HLEN = 3, ST_TMP0 = 4, ST_TMP1 = 5, ST_TMP2 = 6, ST_NCAND = 7,
        ST_CAND = 8 /* 64 candidate item indices */, ST_CAND_SORTED = 72 /* 64 */, ST_NSHORT = 136, ST_NLONG = 137,
-       ST_PULL_L = 138, ST_NBLK = 139 };
-static_assert(ST_NBLK < kStateWords, "state words");
+       ST_PULL_L = 138, ST_NBLK = 139, ST_ENTRIES = 140, ST_ROWS = 141 };
+static_assert(ST_ROWS < kStateWords, "state words");
 constexpr uint32_t kMaxCand = 64;
 
 SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
@@ -176,7 +176,7 @@ SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
   l.rt_pre = (uint32_t*)(smem + L.rt_pre);
   l.dots = (float*)(smem + L.dots);
   l.order = (uint16_t*)(smem + L.order);
-  l.stage = smem + L.q_bits;
+  l.lookup = smem + L.q_bits;
   l.uni = smem + L.uni;
   l.part = (uint32_t*)(smem + L.part);
   l.st = (uint32_t*)(smem + L.st);
@@ -198,17 +198,11 @@ SGPU_DEV void load_query(const Lds& s, const BatchView& qb, uint32_t q, uint32_t
 }
 
 // Query lookup table layouts (device_types.hpp: LK_*).
-// (Re)builds the query lookup table used by the scoring loop. Its LDS region doubles as stage-1
-// staging, so it is cleared and filled between stage 1 and stage 2.
+// Fills the query lookup table used by the scoring loop (cleared during stage 1, lookup_clear).
 //   dense : one byte per vocabulary id: 1 + rank of the id in the query, 0 = absent
 //   bitmap: {32 vocabulary bits, rank of the word's first query component} per 32 ids
 template <int NT, int LK>
 SGPU_DEV void build_lookup(const Lds& s, uint32_t dim, uint32_t nnz) {
-  uint32_t* z = (uint32_t*)s.stage;
-  const uint32_t words = (dim + 31) / 32;
-  const uint32_t nz = LK == LK_DENSE ? (dim + 1 + 3) / 4 : (LK == LK_PACKED ? 2 * words : words);   // split: bits only
-  for (uint32_t i = threadIdx.x; i < nz; i += NT) z[i] = 0;
-  __syncthreads();
   for (uint32_t j = threadIdx.x; j < nnz; j += NT) {
     const uint32_t c = s.q_comp[j];
     if (LK == LK_DENSE) {
@@ -271,8 +265,12 @@ SGPU_DEV void build_row_table(const Lds& s, const DevView& ix, uint32_t nnz, uin
       start = ix.row_ptr[lo];
       len = (uint32_t)(ix.row_ptr[lo + 1] - start);
     }
-    s.rt_start[l * qn + j] = start;
-    s.rt_pre[l * (qn + 1) + j + 1] = len;   // turned into a prefix below
+    if (len) {   // work counters (entries, matched rows)
+      atomicAdd(&s.st[ST_ENTRIES], len);
+      atomicAdd(&s.st[ST_ROWS], 1u);
+    }
+    s.rt_start[l * qn + j] = (start << 16) | (uint64_t)len;   // a row has at most one entry per block: len <= 65535
+    s.rt_pre[l * (qn + 1) + j + 1] = (len + 63u) >> 6;        // 64-entry chunks; turned into a prefix below
   }
   __syncthreads();
   // per-list prefix over the query components (wave w handles lists w, w+NW, ...)
@@ -282,14 +280,9 @@ SGPU_DEV void build_row_table(const Lds& s, const DevView& ix, uint32_t nnz, uin
     uint32_t carry = 0;
     for (uint32_t j0 = 0; j0 < nnz; j0 += 64) {
       const uint32_t j = j0 + lane;
-      uint32_t x = j < nnz ? pre[j + 1] : 0;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d);
-        if (lane >= (uint32_t)d) x += y;
-      }
+      const uint32_t x = wave_inclusive_scan(j < nnz ? pre[j + 1] : 0);
       if (j < nnz) pre[j + 1] = x + carry;
-      carry += __shfl(x, 63);
+      carry += readlane_u(x, 63);
     }
     if (lane == 0) pre[0] = 0;
   }
@@ -305,129 +298,156 @@ SGPU_DEV void build_row_table(const Lds& s, const DevView& ix, uint32_t nnz, uin
   __syncthreads();
 }
 
-// Computes dots for lists [0, nl). stage_cap = staging entries (6 bytes each) available from the
-// start of the lookup-table region to the end of the union region (the lookup table is only
-// needed in stage 2 and is rebuilt after this stage).
-// (a) copy: the whole workgroup streams the matched rows' (block id, dequantised value) entries
-//     from HBM with 8 independent entries in flight per thread, multiplies by the query weight and
-//     parks (block id, product) in LDS. The value array holds code*quant + min computed once at
-//     upload with the reference's roundings (src/quantized_summary.rs:102-104); the product
-//     `* qv` and the accumulation below follow :107-108. No FMA anywhere.
-// (b) accumulate: one wavefront per list adds the products row by row, in ascending query
-//     component order, to the list's accumulators (LDS only, in-order DS pipeline).
-struct StageBuf {   // one staging buffer: products and block ids of `cap_l` entries per list
-  float* prod;
-  uint16_t* bid;
-};
-
-// copy of one window [w0, w0 + cap_l) of every list's flattened matched entries into `sb`, by
-// threads tid = 0..nthreads-1: every thread takes SU consecutive positions of one list's window
-// (one row lookup by binary search in LDS, a short forward walk for the rest), then SU independent
-// HBM loads.
-template <int SU>
-SGPU_DEV void stage_copy(const Lds& s, const DevView& ix, const StageBuf& sb, uint32_t nnz, uint32_t nl,
-                         uint32_t qn, uint32_t cap_l, uint32_t inv_cap, uint32_t w0, uint32_t tid,
-                         uint32_t nthreads) {
-  const uint32_t span = nl * cap_l;
-  for (uint32_t base = tid * SU; base < span; base += SU * nthreads) {
-    uint32_t l = __umulhi(base, inv_cap);
-    uint32_t r = base - l * cap_l;
-    if (r >= cap_l) {
-      r -= cap_l;
-      ++l;
-    }
-    const uint32_t* pre = s.rt_pre + l * (qn + 1);
-    const uint64_t* rts = s.rt_start + l * qn;
-    const uint32_t e_l = pre[nnz];
-    const uint32_t f0 = w0 + r;
-    if (f0 >= e_l) continue;
-    uint32_t lo = 0, hi = nnz;   // last row j with pre[j] <= f0
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (pre[mid] <= f0) lo = mid; else hi = mid;
-    }
-    uint64_t g[SU];
-    float qv[SU];
-    bool ok[SU];
-#pragma unroll
-    for (int u = 0; u < SU; ++u) {
-      const uint32_t f = f0 + (uint32_t)u;
-      ok[u] = f < e_l;
-      while (lo + 1 < nnz && pre[lo + 1] <= f) ++lo;
-      g[u] = ok[u] ? rts[lo] + (f - pre[lo]) : 0ull;
-      qv[u] = s.q_val[lo];
-    }
-    uint32_t bid[SU];
-    float deq[SU];
-#pragma unroll
-    for (int u = 0; u < SU; ++u) {
-      bid[u] = ok[u] ? (uint32_t)ix.sum_bid[g[u]] : 0u;
-      deq[u] = ok[u] ? ix.sum_deq[g[u]] : 0.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < SU; ++u) {
-      if (ok[u]) {
-        sb.prod[base + (uint32_t)u] = __fmul_rn(deq[u], qv[u]);
-        sb.bid[base + (uint32_t)u] = (uint16_t)bid[u];
-      }
-    }
-  }
+// QuantizedSummary::distances for lists [0, nl): one wavefront per list streams the list's matched
+// rows in ascending query-component order, 64 entries (one chunk of one row) per step:
+//     acc[block] += (code * quant + min) * query_weight          (src/quantized_summary.rs:96-108)
+// `code * quant + min` is computed once at upload with the reference's roundings (sum_deq); the
+// product and the addition are separately rounded (no FMA). Block ids are distinct within a row,
+// so the lanes of a step never collide, and a wavefront's LDS operations execute in issue order,
+// so every accumulator sees its additions in ascending component order - the reference's order,
+// bit for bit. The (block id, value) loads of the next kDepth steps are in flight while a step
+// accumulates, so the HBM latency is paid once per list rather than once per row.
+// Wavefronts without a list clear the query lookup table meanwhile (lookup_clear).
+template <int LK>
+SGPU_DEV void lookup_clear(const Lds& s, uint32_t dim, uint32_t tid, uint32_t nthreads) {
+  uint32_t* z = (uint32_t*)s.lookup;
+  const uint32_t words = (dim + 31) / 32;
+  const uint32_t nz = LK == LK_DENSE ? (dim + 1 + 3) / 4 : (LK == LK_PACKED ? 2 * words : words);   // split: bits only
+  for (uint32_t i = tid; i < nz; i += nthreads) z[i] = 0;
 }
 
-// one wavefront adds list l's staged window to its accumulators, row by row in ascending query
-// component order. Block ids are distinct within a row, so lanes never collide; a wavefront's DS
-// operations execute in issue order, so each accumulator sees the reference's order of additions.
-SGPU_DEV void stage_accumulate(const Lds& s, const StageBuf& sb, uint32_t nnz, uint32_t qn, uint32_t cap_l,
-                               uint32_t w0, uint32_t l) {
-  const uint32_t lane = threadIdx.x & 63;
+#ifndef SGPU_STREAM_DEPTH
+#define SGPU_STREAM_DEPTH 16
+#endif
+SGPU_DEV uint32_t uniform_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+SGPU_DEV void stream_list_dots(const Lds& s, const DevView& ix, uint32_t nnz_, uint32_t qn, uint32_t l_) {
+  constexpr int kDepth = SGPU_STREAM_DEPTH;
+  const uint32_t lane = lane_id();
+  // wave-uniform values, pinned to scalar registers so that the step bookkeeping runs on the SALU
+  const uint32_t nnz = uniform_u(nnz_), l = uniform_u(l_);
   float* acc = s.dots + s.sel_doff[l];
-  const float* sp = sb.prod + l * cap_l;
-  const uint16_t* sbid = sb.bid + l * cap_l;
-  const uint32_t* pre = s.rt_pre + l * (qn + 1);
-  for (uint32_t j = 0; j < nnz; ++j) {
-    const uint32_t p0 = pre[j], p1 = pre[j + 1];
-    const uint32_t a = p0 > w0 ? p0 : w0;
-    const uint32_t b = p1 < w0 + cap_l ? p1 : w0 + cap_l;
-    for (uint32_t f = a + lane; f < b; f += 64) {
-      const uint32_t bid = sbid[f - w0];
-      acc[bid] = __fadd_rn(acc[bid], sp[f - w0]);
+  const uint64_t* rts = s.rt_start + l * qn;
+  const uint32_t* cpre = s.rt_pre + l * (qn + 1);
+  for (uint32_t jb = 0; jb < nnz; jb += 64) {   // rows in blocks of 64: lane i keeps row jb + i
+    const uint32_t nj = nnz - jb < 64u ? nnz - jb : 64u;
+    const bool has = lane < nj;
+    const uint64_t r = has ? rts[jb + lane] : 0ull;
+    const uint32_t r_lo = (uint32_t)r, r_hi = (uint32_t)(r >> 32);
+    const uint32_t c0 = cpre[jb + (has ? lane : nj)];   // first chunk of the row; lanes >= nj hold the block's end
+    const float w = has ? s.q_val[jb + lane] : 0.0f;
+    const uint32_t t_begin = readlane_u(c0, 0);
+    const uint32_t t_end = uniform_u(cpre[jb + nj]);
+    for (uint32_t tb = t_begin; tb < t_end; tb += 64) {   // chunks in blocks of 64: lane i describes chunk tb + i
+      const uint32_t cnt = t_end - tb < 64u ? t_end - tb : 64u;
+#ifdef SGPU_PROF_STAGE1
+      const uint64_t ta_ = clock64();
+#endif
+      uint32_t d_lo, d_hn;
+      float d_q;
+      {
+        const uint32_t x = tb + lane;
+        uint32_t lo = 0, hi = 64;   // the row owning chunk x: the last j with c0[j] <= x
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if ((uint32_t)__shfl((int)c0, (int)mid) <= x) lo = mid; else hi = mid;
+        }
+        const uint32_t rl = (uint32_t)__shfl((int)r_lo, (int)lo), rh = (uint32_t)__shfl((int)r_hi, (int)lo);
+        const uint32_t u = x - (uint32_t)__shfl((int)c0, (int)lo);
+        const uint32_t len = rl & 0xffffu;
+        const uint64_t g = ((((uint64_t)rh << 32) | rl) >> 16) + (uint64_t)u * 64u;
+        uint32_t n = len - u * 64u;
+        n = n < 64u ? n : 64u;
+        if (lane >= cnt) n = 0;
+        d_lo = (uint32_t)g;
+        d_hn = (uint32_t)(g >> 32) | (n << 16);   // entry offsets are below 2^48
+        d_q = __shfl(w, (int)lo);
+      }
+      uint32_t bid[kDepth];
+      float prod[kDepth];
+      bool ok[kDepth];
+      auto fetch = [&](uint32_t i, int d) {
+        ok[d] = false;
+        bid[d] = 0;
+        prod[d] = 0.0f;
+        if (i < cnt) {
+          const uint32_t hn = readlane_u(d_hn, i);
+          const uint64_t g = ((((uint64_t)(hn & 0xffffu)) << 32) | readlane_u(d_lo, i)) + lane;
+          ok[d] = lane < (hn >> 16);
+          if (ok[d]) {
+            bid[d] = (uint32_t)ix.sum_bid[g];
+            prod[d] = ix.sum_deq[g];   // multiplied by the row's query weight when consumed
+          }
+        }
+      };
+#ifdef SGPU_PROF_STAGE1
+      const uint64_t tb_ = clock64();
+#endif
+#pragma unroll
+      for (int d = 0; d < kDepth; ++d) fetch((uint32_t)d, d);
+#ifdef SGPU_PROF_STAGE1
+      const uint64_t tc_ = clock64();
+#endif
+      for (uint32_t i = 0; i < cnt; i += kDepth) {
+#pragma unroll
+        for (int d = 0; d < kDepth; ++d) {
+          // (a return-less LDS float add, ds_add_f32, rounds identically - tools/ubench/lds_fadd_check.hip -
+          // but costs ~350 cycles per wavefront instruction against ~100 for this read-add-write;
+          // sending the idle lanes to a spare accumulator instead of branching is slower still)
+          if (ok[d]) acc[bid[d]] = __fadd_rn(acc[bid[d]], __fmul_rn(prod[d], readlane_f(d_q, i + (uint32_t)d)));
+          fetch(i + (uint32_t)d + kDepth, d);
+        }
+      }
+#ifdef SGPU_PROF_STAGE1
+      if (l == 0 && lane == 0) {
+        const uint64_t td_ = clock64();
+        s.st[ST_CAND + 4] += (uint32_t)(tb_ - ta_);
+        s.st[ST_CAND + 5] += (uint32_t)(tc_ - tb_);
+        s.st[ST_CAND + 6] += (uint32_t)(td_ - tc_);
+        s.st[ST_CAND + 7] += 1;
+      }
+#endif
     }
   }
 }
 
-// Computes dots for lists [0, nl). stage_cap = staging entries (6 bytes each) available from the
-// start of the lookup-table region to the end of the union region (the lookup table is only
-// needed in stage 2 and is rebuilt after this stage).
-//   copy      : the matched rows' (block id, dequantised value) entries stream from HBM, are
-//               multiplied by the query weight and parked in LDS. The value array holds
-//               code*quant + min computed once at upload with the reference's roundings
-//               (src/quantized_summary.rs:102-104); `* qv` and `+=` follow :107-108. No FMA.
-//   accumulate: one wavefront per list (stage_accumulate).
-// (Measured and dropped: splitting the staging area in two so that half the wavefronts copy window
-// r + 1 while the others accumulate window r — the copy, not the accumulation, is the long pole.)
-template <int NT>
-SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32_t nl, uint32_t qn,
-                           uint32_t stage_cap) {
+template <int NT, int LK>
+SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32_t nl, uint32_t qn, uint32_t dim,
+                           bool want_lookup) {
   const uint32_t wave = threadIdx.x >> 6;
   constexpr uint32_t NW = NT / 64;
-  constexpr int SU = 8;
   const uint32_t total_blocks = s.sel_doff[nl];
   for (uint32_t i = threadIdx.x; i < total_blocks; i += NT) s.dots[i] = 0.0f;
-  uint32_t emax = 0;
-  for (uint32_t l = 0; l < nl; ++l) {
-    const uint32_t e = s.rt_pre[l * (qn + 1) + nnz];
-    emax = e > emax ? e : emax;
-  }
-  const uint32_t cap_l = (stage_cap / nl) & ~63u;   // staging window per list
-  const uint32_t inv_cap = 0xffffffffu / cap_l;
-  StageBuf sb;
-  sb.prod = (float*)s.stage;
-  sb.bid = (uint16_t*)(sb.prod + (size_t)cap_l * nl);
   __syncthreads();
-  for (uint32_t w0 = 0; w0 < emax; w0 += cap_l) {
-    stage_copy<SU>(s, ix, sb, nnz, nl, qn, cap_l, inv_cap, w0, threadIdx.x, NT);
-    __syncthreads();
-    for (uint32_t l = wave; l < nl; l += NW) stage_accumulate(s, sb, nnz, qn, cap_l, w0, l);
+  const uint32_t busy = nl < NW ? nl : NW;   // wavefronts that own a list
+#ifdef SGPU_PROF_STAGE1
+  if (threadIdx.x < 8) s.st[ST_CAND + threadIdx.x] = 0;
+  __syncthreads();
+#endif
+  if (wave < busy) {
+#ifdef SGPU_PROF_STAGE1
+    const uint64_t t0_ = clock64();
+#endif
+    // a long serial instruction stream on one wavefront per list, while the rest of the workgroup
+    // waits: take the SIMD's issue slots ahead of the co-resident workgroup's scoring wavefronts
+    __builtin_amdgcn_s_setprio(3);
+    for (uint32_t l = wave; l < nl; l += NW) stream_list_dots(s, ix, nnz, qn, l);
+    __builtin_amdgcn_s_setprio(0);
+#ifdef SGPU_PROF_STAGE1
+    if (threadIdx.x == 0) {
+      s.st[ST_CAND + 0] = s.st[ST_CAND + 4] >> 4;
+      s.st[ST_CAND + 1] = s.st[ST_CAND + 5] >> 4;
+      s.st[ST_CAND + 2] = s.st[ST_CAND + 6] >> 4;
+      s.st[ST_CAND + 3] = s.st[ST_CAND + 7];
+    }
+#endif
+  } else if (want_lookup) {
+    lookup_clear<LK>(s, dim, threadIdx.x - busy * 64u, NT - busy * 64u);
+  }
+  __syncthreads();
+  if (want_lookup && busy == NW) {
+    lookup_clear<LK>(s, dim, threadIdx.x, NT);
     __syncthreads();
   }
 }
@@ -983,6 +1003,7 @@ SGPU_DEV void replay_round(RegHeap<KR>& heap, const ChunkBufs& cb, const Lds& s,
                            uint32_t n_items, uint32_t* bitmap, uint32_t& decided_blk, bool block_starts_at_0,
                            WorkCount& wc, const float* dots, bool dups = false) {
   uint32_t live_items = 0;
+  __builtin_amdgcn_s_setprio(3);   // serial section: seven wavefronts wait for this one
   const uint32_t nc = s.st[ST_NCAND];
   if (!p.use_bitmap && heap.len == p.k && nc <= kMaxCand) {
     // (the heap was full when the round started: phase B collected every item that can matter)
@@ -1001,6 +1022,7 @@ SGPU_DEV void replay_round(RegHeap<KR>& heap, const ChunkBufs& cb, const Lds& s,
     s.st[ST_TMP1] = live_items;
     s.st[ST_NSHORT] = 0;   // the next round's class lists start empty
   }
+  __builtin_amdgcn_s_setprio(0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1057,10 +1079,15 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
 #ifdef SGPU_PROF_REPLAY
     uint32_t xr_cand = 0, xr_full = 0, xr_nfull = 0;
 #endif
+#ifdef SGPU_PROF_STAGE1
+    uint32_t xs0 = 0, xs1 = 0, xs2 = 0;
+#endif
     if (threadIdx.x == 0) {
       s.st[ST_HLEN] = 0;
       s.st[ST_THR] = 0;
       s.st[ST_NSHORT] = 0;
+      s.st[ST_ENTRIES] = 0;
+      s.st[ST_ROWS] = 0;
     }
     __syncthreads();
     if (p.mode == MODE_DOTS) {   // sgpu_summary_distances: aim stage 1 at one given list
@@ -1084,14 +1111,15 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
       // ---- stage 1 ----
       build_row_table<CT, NT>(s, ix, nnz, nl, L.qn);
       TICK(1);
-      if (qb.out_stats && threadIdx.x == 0) {
-        for (uint32_t l = 0; l < nl; ++l) {
-          const uint32_t* pre = s.rt_pre + l * (L.qn + 1);
-          st_entries += pre[nnz];
-          for (uint32_t j = 0; j < nnz; ++j) st_rows += pre[j + 1] != pre[j];
-        }
+      if (threadIdx.x == 0) {
+        st_entries = s.st[ST_ENTRIES];
+        st_rows = s.st[ST_ROWS];
       }
-      summary_dots<NT>(s, ix, nnz, nl, L.qn, p.stage_cap);
+      summary_dots<NT, LK>(s, ix, nnz, nl, L.qn, ix.dim, p.mode != MODE_DOTS);
+#ifdef SGPU_PROF_STAGE1
+      xs0 = s.st[ST_CAND + 0]; xs1 = s.st[ST_CAND + 1]; xs2 = s.st[ST_CAND + 2];
+      __syncthreads();
+#endif
       TICK(2);
 
       if (p.mode == MODE_DOTS) {   // sgpu_summary_distances: dump the dots of list 0
@@ -1372,6 +1400,9 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
       os[12] = blockIdx.x;
 #ifdef SGPU_PROF_REPLAY
       os[13] = xr_cand; os[14] = xr_full; os[15] = xr_nfull;
+#endif
+#ifdef SGPU_PROF_STAGE1
+      os[13] = xs0; os[14] = xs1; os[15] = xs2;
 #endif
     }
 #undef TICK
