@@ -897,70 +897,86 @@ SGPU_DEV void replay_candidates(RegHeap<KR>& heap, const ChunkBufs& cb, const ui
 
 // Phase B: speculative scoring of the round's items, 16 lanes per document. Phase A sorted the
 // items into two classes by length (ChunkBufs::it_ord): documents of at most 128 elements (one
-// slice of 8 elements per lane; two thirds of a SPLADE-shaped collection) are scored FOUR at a time
-// per lane group, longer ones two at a time with their first two slices fetched up front. Either
-// way a lane group keeps 4 slices (128 B per lane) in flight, which is what the register budget of
-// 2 x 512 threads per CU allows; the short class just has no half-empty second slices among them.
-// Groups pull documents from a shared counter (a step ahead of their use). When the heap is
-// already full (and no visited bitmap is kept) the items scoring above the round's starting
-// threshold are collected for replay_candidates.
+// slice of 8 elements per lane; two thirds of a SPLADE-shaped collection) occupy one slot of 8
+// registers each and a lane group keeps FOUR of them in flight; longer ones take two slices and a
+// group keeps two in flight (both ways 128 B per lane, what the register budget of 2 x 512 threads
+// per CU allows). The slots ROTATE: as soon as a slot's document is scored the next document's
+// loads are issued into it, so the memory pipe stays busy while the other slots are being scored.
+// The loads are unconditional (idle lanes re-read the record's first bytes): nothing but
+// straight-line code lies between a load and its use, and the compiler's counter waits name
+// exactly the slot they need (vmcnt(6), not vmcnt(0)).
+// Groups pull documents from a shared counter, a batch ahead. When the heap is already full (and
+// no visited bitmap is kept) the items scoring above the round's starting threshold are collected
+// for replay_candidates.
 template <typename CT, int LK, int ND, int NS>
 SGPU_DEV void score_class(const Lds& s, const DevView& ix, const ChunkBufs& cb, const uint16_t* list, int dir,
-                          uint32_t n, uint32_t* pull, bool collect, float thr0, uint32_t& spec_docs) {
+                              uint32_t n, uint32_t* pull, bool collect, float thr0, uint32_t& spec_docs) {
+  if (n == 0) return;
   const uint32_t sub = threadIdx.x & 15;
   float* it_score = (float*)cb.it_ref;
   const uint32_t e0 = sub * 8u;
-  uint32_t i_next = 0;
-  if (sub == 0) i_next = atomicAdd(pull, (uint32_t)ND);
+  uint32_t len[ND], item[ND];
+  const uint8_t* rec[ND];
+  DocChunk<CT> d[ND][NS];
+  auto issue = [&](int u, uint32_t iu) {
+    const bool has = iu < n;
+    const uint32_t it = (uint32_t)list[(int)(has ? iu : 0u) * dir];
+    const uint64_t ref = cb.it_ref[it];
+    item[u] = has ? it : 0xffffffffu;
+    len[u] = has ? (uint32_t)(ref & 0xffffu) : 0u;
+    rec[u] = ix.fwd + (has ? (ref >> 16) : 0ull) * 16ull;
+    const uint8_t* val = rec[u] + (size_t)((len[u] + 7u) & ~7u) * sizeof(CT);
+#pragma unroll
+    for (int h = 0; h < NS; ++h) {
+      const uint32_t e = e0 + 128u * h;
+      const bool act = e < len[u];
+      const uint8_t* pc = act ? rec[u] + (size_t)e * sizeof(CT) : rec[u];
+      const uint8_t* pv = act ? val + (size_t)e * 2 : rec[u];
+      d[u][h].c0 = *(const uint4*)pc;
+      if (sizeof(CT) == 4) d[u][h].c1 = *(const uint4*)(pc + 16);
+      d[u][h].v = *(const uint4*)pv;
+    }
+  };
+  auto consume = [&](int u) {
+    float a = 0.0f;
+#pragma unroll
+    for (int h = 0; h < NS; ++h)
+      if (e0 + 128u * h < len[u]) a = accumulate_chunk<CT, LK>(s, d[u][h], e0 + 128u * h, len[u], a);
+    if (NS > 1) {
+      const uint8_t* val = rec[u] + (size_t)((len[u] + 7u) & ~7u) * sizeof(CT);
+      for (uint32_t e = e0 + 128u * NS; e < len[u]; e += 128u) {   // documents longer than 256
+        DocChunk<CT> t;
+        load_chunk<CT>(t, rec[u], val, e);
+        a = accumulate_chunk<CT, LK>(s, t, e, len[u], a);
+      }
+    }
+    a = reduce16(a);
+    spec_docs += (sub == 0 && len[u] != 0);
+    if (sub == 0 && item[u] != 0xffffffffu) {
+      it_score[2 * item[u] + 1] = a;
+      if (collect && len[u] != 0 && a > thr0) {
+        const uint32_t slot = atomicAdd(&s.st[ST_NCAND], 1u);
+        if (slot < kMaxCand) s.st[ST_CAND + slot] = item[u];
+      }
+    }
+  };
+  uint32_t pulled = 0;
+  if (sub == 0) pulled = atomicAdd(pull, (uint32_t)ND);
+  uint32_t base = row_bcast0(pulled);
+  if (base >= n) return;
+#pragma unroll
+  for (int u = 0; u < ND; ++u) issue(u, base + (uint32_t)u);
   for (;;) {
-    const uint32_t i = row_bcast0(i_next);
-    if (i >= n) break;
-    // the pull for the following step is issued before this step's work
-    if (sub == 0) i_next = atomicAdd(pull, (uint32_t)ND);
-    uint32_t len[ND], item[ND];
-    const uint8_t* rec[ND];
-    const uint8_t* val[ND];
-    DocChunk<CT> d[ND][NS];
+    if (sub == 0) pulled = atomicAdd(pull, (uint32_t)ND);   // the batch that refills the slots
+    consume(0);
+    base = row_bcast0(pulled);
+    issue(0, base);
 #pragma unroll
-    for (int u = 0; u < ND; ++u) {
-      const uint32_t iu = i + (uint32_t)u;
-      const bool has = iu < n;
-      item[u] = has ? (uint32_t)list[(int)iu * dir] : 0xffffffffu;
-      const uint64_t ref = has ? cb.it_ref[item[u]] : 0ull;
-      len[u] = (uint32_t)(ref & 0xffffu);
-      rec[u] = ix.fwd + (ref >> 16) * 16ull;
-      val[u] = rec[u] + (size_t)((len[u] + 7u) & ~7u) * sizeof(CT);
+    for (int u = 1; u < ND; ++u) {
+      consume(u);
+      issue(u, base + (uint32_t)u);
     }
-#pragma unroll
-    for (int u = 0; u < ND; ++u) {
-#pragma unroll
-      for (int h = 0; h < NS; ++h) {
-        d[u][h].c0 = d[u][h].c1 = d[u][h].v = make_uint4(0, 0, 0, 0);
-        if (e0 + 128u * h < len[u]) load_chunk<CT>(d[u][h], rec[u], val[u], e0 + 128u * h);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < ND; ++u) {
-      float a = 0.0f;
-#pragma unroll
-      for (int h = 0; h < NS; ++h)
-        if (e0 + 128u * h < len[u]) a = accumulate_chunk<CT, LK>(s, d[u][h], e0 + 128u * h, len[u], a);
-      if (NS > 1) {
-        for (uint32_t e = e0 + 128u * NS; e < len[u]; e += 128u) {   // documents longer than 256
-          load_chunk<CT>(d[u][0], rec[u], val[u], e);
-          a = accumulate_chunk<CT, LK>(s, d[u][0], e, len[u], a);
-        }
-      }
-      a = reduce16(a);
-      spec_docs += (sub == 0 && len[u] != 0);
-      if (sub == 0 && item[u] != 0xffffffffu) {
-        it_score[2 * item[u] + 1] = a;
-        if (collect && len[u] != 0 && a > thr0) {
-          const uint32_t slot = atomicAdd(&s.st[ST_NCAND], 1u);
-          if (slot < kMaxCand) s.st[ST_CAND + slot] = item[u];
-        }
-      }
-    }
+    if (base >= n) break;   // every slot was refilled with nothing
   }
 }
 
