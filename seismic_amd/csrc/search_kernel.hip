@@ -9,18 +9,18 @@
 //            -> the posting lists to walk, in order.
 //   stage 1  hot loop A, QuantizedSummary::distances (src/quantized_summary.rs:64-160)
 //            for ALL selected lists at once (a pure function of the query):
-//            matching summary rows are located by binary search; their (block id,
-//            dequantised value) entries are streamed HBM -> LDS by the whole
-//            workgroup (8 independent loads in flight per thread), multiplied by
-//            the query weight on the way; then one wavefront per list adds the
-//            products row by row to f32 accumulators in LDS. A wavefront issues its
-//            DS operations in order and block ids are distinct within a row, so
-//            every accumulator receives its additions in ascending query component
-//            order with the reference's roundings ((code*quant + min) * qv, then
-//            +=; no FMA; code*quant + min is precomputed once at upload): BIT-EXACT.
-//   lookup   between the stages the query lookup table is built in the LDS region
-//            stage 1 used for staging: one byte per vocabulary id (1 + rank in the
-//            query, 0 = absent) when it fits, else {32 bits, rank} per 32 ids.
+//            matching summary rows are located by binary search; one wavefront per
+//            list then streams the list's matched rows in ascending query component
+//            order, 64 (block id, dequantised value) entries per step, the loads of
+//            the next 16 steps in flight, and adds value * weight to f32
+//            accumulators in LDS. A wavefront issues its DS operations in order and
+//            block ids are distinct within a row, so every accumulator receives its
+//            additions in ascending query component order with the reference's
+//            roundings ((code*quant + min) * qv, then +=; no FMA; code*quant + min
+//            is precomputed once at upload): BIT-EXACT.
+//   lookup   the query lookup table (cleared during stage 1 by the wavefronts that
+//            have no list): one byte per vocabulary id (1 + rank in the query,
+//            0 = absent) when it fits, else {32 bits, rank} per 32 ids.
 //   stage 2  hot loop B, PostingList::search / sort_and_search /
 //            evaluate_posting_block (src/posting_list.rs:115-215), list by list.
 //            The reference's skip test reads the LIVE k-th best score, so the set of
@@ -31,8 +31,9 @@
 //                  compacts the survivors in traversal order, under an item budget;
 //              (b) fetches their postings and scores every document SPECULATIVELY:
 //                  16 lanes per document, 16-byte loads of the record (components |
-//                  f16 values), two documents and two 128-element slices in flight
-//                  per lane group, documents pulled from a shared counter;
+//                  f16 values); per lane group four documents of <= 128 elements
+//                  (or two longer ones) in flight in rotating register slots,
+//                  documents pulled from a shared counter;
 //              (c) REPLAYS the reference's sequential decisions on one wavefront over
 //                  the (block dot, doc score) table in LDS: same skip tests with the
 //                  live threshold, same heap pushes in the same order. Once the heap
