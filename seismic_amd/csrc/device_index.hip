@@ -204,6 +204,21 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     }
     if ((st = dev_copy(d, h.sum_bid.data(), h.sum_bid.size(), &d->view.sum_bid)) != SGPU_OK) return bail(st);
     {
+      // split point of every summary row at half the list's block ids (rows are ascending in block
+      // id, validate_desc): stage 1 gives each half of a list to its own wavefront
+      std::vector<uint16_t> mid(h.n_rows());
+      for (uint64_t c = 0; c < h.dim; ++c) {
+        const uint64_t nb = h.list_block_start[c + 1] - h.list_block_start[c];
+        const uint16_t half = (uint16_t)((nb + 1) / 2);
+        for (uint64_t r = h.list_row_start[c]; r < h.list_row_start[c + 1]; ++r) {
+          const uint16_t* b = h.sum_bid.data() + h.row_ptr[r];
+          const uint16_t* e = h.sum_bid.data() + h.row_ptr[r + 1];
+          mid[r] = (uint16_t)(std::lower_bound(b, e, half) - b);
+        }
+      }
+      if ((st = dev_copy(d, mid.data(), mid.size(), &d->view.row_mid)) != SGPU_OK) return bail(st);
+    }
+    {
       // dequantised summary values: code*quant + min with the reference's two roundings
       // (src/quantized_summary.rs:102-104; this file is compiled with -ffp-contract=off)
       std::vector<float> deq(h.n_entries());
@@ -463,7 +478,8 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   L.q_val = o; o += up16((qn + 1) * 4);   // + the 0.0 slot non-matching components resolve to
   L.sel = o; o += up16((6 * qc + 1) * 4);
   L.rt_start = o; o += up16(qc * qn * 8);
-  L.rt_pre = o; o += up16(qc * (qn + 1) * 4);
+  L.rt_mid = o; o += up16(qc * qn * 2);
+  L.rt_pre = o; o += up16(2 * qc * (qn + 1) * 4);   // two streams (block-id halves) per list
   L.dots = o; o += up16(dots_cap * 4);
   L.order = o; o += up16((sp.first_sorted && searching) ? sort_nb * 2 : 0);
   L.part = o; o += up16(2 * (NT / 64 + 1) * 4);   // two scan scratch areas, used alternately

@@ -18,7 +18,9 @@ struct DevView {
   const uint32_t* list_row_start;     // dim + 1
   const void* row_comp;               // n_rows, ascending within a list
   const uint64_t* row_ptr;            // n_rows + 1 (entries can exceed 2^32 on large indexes)
-  const uint16_t* sum_bid;            // n_entries: list-local block id
+  const uint16_t* sum_bid;            // n_entries: list-local block id, ascending within a row
+  const uint16_t* row_mid;            // n_rows: entries of the row whose block id is below half the list's blocks
+                                      //   (stage 1 splits every list between two wavefronts by block id)
   const float* sum_deq;               // n_entries: code*quant + min of the entry's block, rounded as the
                                       //   reference does (src/quantized_summary.rs:102-104), precomputed at upload
   // kNN graph (reference: Knn, src/inverted_index.rs:430-594): flattened neighbour lists, and the
@@ -64,7 +66,7 @@ struct KParams {
 };
 
 struct LdsLayout {   // byte offsets into dynamic LDS, all multiples of 16
-  uint32_t q_comp, q_val, q_bits, q_rank, sel, rt_start, rt_pre, dots, order, uni, part, st;
+  uint32_t q_comp, q_val, q_bits, q_rank, sel, rt_start, rt_mid, rt_pre, dots, order, uni, part, st;
   uint32_t qc, qn;   // capacities: lists per query, components per query
   uint32_t total;
 };

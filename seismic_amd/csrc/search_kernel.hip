@@ -145,7 +145,8 @@ struct Lds {
   uint32_t* sel_r0;     // [QC] first global summary row
   uint32_t* sel_nr;     // [QC] number of summary rows
   uint64_t* rt_start;   // [QC*QN] global entry index of matched row (l, j) (64-bit: > 4 G summary entries)
-  uint32_t* rt_pre;     // [QC*(QN+1)] flattened prefix of matched row lengths
+  uint16_t* rt_mid;     // [QC*QN] split of the row between the list's two block-id halves
+  uint32_t* rt_pre;     // [2*QC*(QN+1)] per (list, half): prefix of the rows' 64-entry chunk counts
   float* dots;
   uint16_t* order;
   uint8_t* lookup;      // start of the query lookup table (whichever layout)
@@ -174,6 +175,7 @@ SGPU_DEV Lds carve(uint8_t* smem, const LdsLayout& L) {
   l.sel_r0 = l.sel_doff + L.qc + 1;
   l.sel_nr = l.sel_r0 + L.qc;
   l.rt_start = (uint64_t*)(smem + L.rt_start);
+  l.rt_mid = (uint16_t*)(smem + L.rt_mid);
   l.rt_pre = (uint32_t*)(smem + L.rt_pre);
   l.dots = (float*)(smem + L.dots);
   l.order = (uint16_t*)(smem + L.order);
@@ -261,22 +263,26 @@ SGPU_DEV void build_row_table(const Lds& s, const DevView& ix, uint32_t nnz, uin
       if (c < target) lo = mid + 1; else hi = mid;
     }
     uint64_t start = 0;
-    uint32_t len = 0;
+    uint32_t len = 0, mid = 0;
     if (lo < s.sel_r0[l] + s.sel_nr[l] && (uint32_t)row_comp[lo] == target) {
       start = ix.row_ptr[lo];
       len = (uint32_t)(ix.row_ptr[lo + 1] - start);
+      mid = ix.row_mid[lo];
     }
     if (len) {   // work counters (entries, matched rows)
       atomicAdd(&s.st[ST_ENTRIES], len);
       atomicAdd(&s.st[ST_ROWS], 1u);
     }
     s.rt_start[l * qn + j] = (start << 16) | (uint64_t)len;   // a row has at most one entry per block: len <= 65535
-    s.rt_pre[l * (qn + 1) + j + 1] = (len + 63u) >> 6;        // 64-entry chunks; turned into a prefix below
+    s.rt_mid[l * qn + j] = (uint16_t)mid;
+    // 64-entry chunks of the two halves [0, mid) and [mid, len); turned into prefixes below
+    s.rt_pre[(2 * l) * (qn + 1) + j + 1] = (mid + 63u) >> 6;
+    s.rt_pre[(2 * l + 1) * (qn + 1) + j + 1] = (len - mid + 63u) >> 6;
   }
   __syncthreads();
-  // per-list prefix over the query components (wave w handles lists w, w+NW, ...)
+  // per-stream prefix over the query components (wave w handles streams w, w+NW, ...)
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t l = wave; l < nl; l += NT / 64) {
+  for (uint32_t l = wave; l < 2 * nl; l += NT / 64) {
     uint32_t* pre = s.rt_pre + l * (qn + 1);
     uint32_t carry = 0;
     for (uint32_t j0 = 0; j0 < nnz; j0 += 64) {
@@ -322,18 +328,26 @@ SGPU_DEV void lookup_clear(const Lds& s, uint32_t dim, uint32_t tid, uint32_t nt
 #endif
 SGPU_DEV uint32_t uniform_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-SGPU_DEV void stream_list_dots(const Lds& s, const DevView& ix, uint32_t nnz_, uint32_t qn, uint32_t l_) {
+SGPU_DEV void stream_list_dots(const Lds& s, const DevView& ix, uint32_t nnz_, uint32_t qn, uint32_t sl_) {
   constexpr int kDepth = SGPU_STREAM_DEPTH;
   const uint32_t lane = lane_id();
   // wave-uniform values, pinned to scalar registers so that the step bookkeeping runs on the SALU
-  const uint32_t nnz = uniform_u(nnz_), l = uniform_u(l_);
+  // stream sl = (list l, half h): the entries of l's rows whose block id lies in l's lower (h = 0) or
+  // upper (h = 1) half. The two streams of a list touch disjoint accumulators.
+  const uint32_t nnz = uniform_u(nnz_), sl = uniform_u(sl_), l = sl >> 1, h = sl & 1u;
   float* acc = s.dots + s.sel_doff[l];
   const uint64_t* rts = s.rt_start + l * qn;
-  const uint32_t* cpre = s.rt_pre + l * (qn + 1);
+  const uint16_t* mids = s.rt_mid + l * qn;
+  const uint32_t* cpre = s.rt_pre + sl * (qn + 1);
   for (uint32_t jb = 0; jb < nnz; jb += 64) {   // rows in blocks of 64: lane i keeps row jb + i
     const uint32_t nj = nnz - jb < 64u ? nnz - jb : 64u;
     const bool has = lane < nj;
-    const uint64_t r = has ? rts[jb + lane] : 0ull;
+    uint64_t r = 0ull;
+    if (has) {   // this half of the row: (first entry) << 16 | entries
+      const uint64_t full = rts[jb + lane];
+      const uint32_t len = (uint32_t)full & 0xffffu, mid = mids[jb + lane];
+      r = h ? ((((full >> 16) + mid) << 16) | (uint64_t)(len - mid)) : (((full >> 16) << 16) | (uint64_t)mid);
+    }
     const uint32_t r_lo = (uint32_t)r, r_hi = (uint32_t)(r >> 32);
     const uint32_t c0 = cpre[jb + (has ? lane : nj)];   // first chunk of the row; lanes >= nj hold the block's end
     const float w = has ? s.q_val[jb + lane] : 0.0f;
@@ -341,9 +355,6 @@ SGPU_DEV void stream_list_dots(const Lds& s, const DevView& ix, uint32_t nnz_, u
     const uint32_t t_end = uniform_u(cpre[jb + nj]);
     for (uint32_t tb = t_begin; tb < t_end; tb += 64) {   // chunks in blocks of 64: lane i describes chunk tb + i
       const uint32_t cnt = t_end - tb < 64u ? t_end - tb : 64u;
-#ifdef SGPU_PROF_STAGE1
-      const uint64_t ta_ = clock64();
-#endif
       uint32_t d_lo, d_hn;
       float d_q;
       {
@@ -382,14 +393,8 @@ SGPU_DEV void stream_list_dots(const Lds& s, const DevView& ix, uint32_t nnz_, u
           }
         }
       };
-#ifdef SGPU_PROF_STAGE1
-      const uint64_t tb_ = clock64();
-#endif
 #pragma unroll
       for (int d = 0; d < kDepth; ++d) fetch((uint32_t)d, d);
-#ifdef SGPU_PROF_STAGE1
-      const uint64_t tc_ = clock64();
-#endif
       for (uint32_t i = 0; i < cnt; i += kDepth) {
 #pragma unroll
         for (int d = 0; d < kDepth; ++d) {
@@ -400,15 +405,6 @@ SGPU_DEV void stream_list_dots(const Lds& s, const DevView& ix, uint32_t nnz_, u
           fetch(i + (uint32_t)d + kDepth, d);
         }
       }
-#ifdef SGPU_PROF_STAGE1
-      if (l == 0 && lane == 0) {
-        const uint64_t td_ = clock64();
-        s.st[ST_CAND + 4] += (uint32_t)(tb_ - ta_);
-        s.st[ST_CAND + 5] += (uint32_t)(tc_ - tb_);
-        s.st[ST_CAND + 6] += (uint32_t)(td_ - tc_);
-        s.st[ST_CAND + 7] += 1;
-      }
-#endif
     }
   }
 }
@@ -421,28 +417,10 @@ SGPU_DEV void summary_dots(const Lds& s, const DevView& ix, uint32_t nnz, uint32
   const uint32_t total_blocks = s.sel_doff[nl];
   for (uint32_t i = threadIdx.x; i < total_blocks; i += NT) s.dots[i] = 0.0f;
   __syncthreads();
-  const uint32_t busy = nl < NW ? nl : NW;   // wavefronts that own a list
-#ifdef SGPU_PROF_STAGE1
-  if (threadIdx.x < 8) s.st[ST_CAND + threadIdx.x] = 0;
-  __syncthreads();
-#endif
+  const uint32_t ns = 2 * nl;                // streams: two block-id halves per list
+  const uint32_t busy = ns < NW ? ns : NW;   // wavefronts that own a stream
   if (wave < busy) {
-#ifdef SGPU_PROF_STAGE1
-    const uint64_t t0_ = clock64();
-#endif
-    // a long serial instruction stream on one wavefront per list, while the rest of the workgroup
-    // waits: take the SIMD's issue slots ahead of the co-resident workgroup's scoring wavefronts
-    __builtin_amdgcn_s_setprio(3);
-    for (uint32_t l = wave; l < nl; l += NW) stream_list_dots(s, ix, nnz, qn, l);
-    __builtin_amdgcn_s_setprio(0);
-#ifdef SGPU_PROF_STAGE1
-    if (threadIdx.x == 0) {
-      s.st[ST_CAND + 0] = s.st[ST_CAND + 4] >> 4;
-      s.st[ST_CAND + 1] = s.st[ST_CAND + 5] >> 4;
-      s.st[ST_CAND + 2] = s.st[ST_CAND + 6] >> 4;
-      s.st[ST_CAND + 3] = s.st[ST_CAND + 7];
-    }
-#endif
+    for (uint32_t sl = wave; sl < ns; sl += NW) stream_list_dots(s, ix, nnz, qn, sl);
   } else if (want_lookup) {
     lookup_clear<LK>(s, dim, threadIdx.x - busy * 64u, NT - busy * 64u);
   }
@@ -631,20 +609,10 @@ SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0
     // one byte per vocabulary id: 1 + rank in the query, 0 = absent (-> q_val[-1] == 0.0).
     // Padding components carry the sentinel id `dim`, whose byte is always 0: no length test.
     uint32_t r[8];
-#if defined(SGPU_EXP) && SGPU_EXP == 1   // experiment: no lookups at all
-#pragma unroll
-    for (int i = 0; i < 8; ++i) qv[i] = __uint_as_float(c[i]);
-#elif defined(SGPU_EXP) && SGPU_EXP == 2   // experiment: first lookup only
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r[i] = s.q_idx[c[i]];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) qv[i] = __uint_as_float(r[i]);
-#else
 #pragma unroll
     for (int i = 0; i < 8; ++i) r[i] = s.q_idx[c[i]];
 #pragma unroll
     for (int i = 0; i < 8; ++i) qv[i] = s.q_val[(int)r[i] - 1];
-#endif
   } else {
     uint2 w[8];
 #pragma unroll
@@ -1020,7 +988,6 @@ SGPU_DEV void replay_round(RegHeap<KR>& heap, const ChunkBufs& cb, const Lds& s,
                            uint32_t n_items, uint32_t* bitmap, uint32_t& decided_blk, bool block_starts_at_0,
                            WorkCount& wc, const float* dots, bool dups = false) {
   uint32_t live_items = 0;
-  __builtin_amdgcn_s_setprio(3);   // serial section: seven wavefronts wait for this one
   const uint32_t nc = s.st[ST_NCAND];
   if (!p.use_bitmap && heap.len == p.k && nc <= kMaxCand) {
     // (the heap was full when the round started: phase B collected every item that can matter)
@@ -1039,7 +1006,6 @@ SGPU_DEV void replay_round(RegHeap<KR>& heap, const ChunkBufs& cb, const Lds& s,
     s.st[ST_TMP1] = live_items;
     s.st[ST_NSHORT] = 0;   // the next round's class lists start empty
   }
-  __builtin_amdgcn_s_setprio(0);
 }
 
 // ---------------------------------------------------------------------------
@@ -1093,12 +1059,6 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
     heap.reset();
     wc = WorkCount{0, 0, 0, 0};
     uint32_t spec_docs = 0, st_entries = 0, st_rows = 0;
-#ifdef SGPU_PROF_REPLAY
-    uint32_t xr_cand = 0, xr_full = 0, xr_nfull = 0;
-#endif
-#ifdef SGPU_PROF_STAGE1
-    uint32_t xs0 = 0, xs1 = 0, xs2 = 0;
-#endif
     if (threadIdx.x == 0) {
       s.st[ST_HLEN] = 0;
       s.st[ST_THR] = 0;
@@ -1133,10 +1093,6 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
         st_rows = s.st[ST_ROWS];
       }
       summary_dots<NT, LK>(s, ix, nnz, nl, L.qn, ix.dim, p.mode != MODE_DOTS);
-#ifdef SGPU_PROF_STAGE1
-      xs0 = s.st[ST_CAND + 0]; xs1 = s.st[ST_CAND + 1]; xs2 = s.st[ST_CAND + 2];
-      __syncthreads();
-#endif
       TICK(2);
 
       if (p.mode == MODE_DOTS) {   // sgpu_summary_distances: dump the dots of list 0
@@ -1284,22 +1240,9 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
             __syncthreads();
             TICK(7);
             // (e) exact replay on wavefront 0
-#ifdef SGPU_PROF_REPLAY
-            {
-              const uint32_t nc_ = s.st[ST_NCAND];
-              const bool cand_ = s.st[ST_HLEN] == p.k && nc_ <= kMaxCand;
-              const uint64_t t0_ = clock64();
-              if (wave == 0) replay_round<KR>(heap, cb, s, p, n_items, bitmap, decided_blk, piece == 0, wc, dots);
-              const uint32_t dt_ = (uint32_t)((clock64() - t0_) >> 4);
-              if (cand_) { xr_cand += dt_; } else { xr_full += dt_; xr_nfull += 1; }
-              __syncthreads();
-              TICK(8);
-            }
-#else
             if (wave == 0) replay_round<KR>(heap, cb, s, p, n_items, bitmap, decided_blk, piece == 0, wc, dots);
             __syncthreads();
             TICK(8);
-#endif
           }
           pos = next_pos;
           // adapt the speculation budget to how much of the last round the replay kept
@@ -1415,12 +1358,6 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
 #pragma unroll
       for (int i = 0; i < 12; ++i) os[i] = prof[i];
       os[12] = blockIdx.x;
-#ifdef SGPU_PROF_REPLAY
-      os[13] = xr_cand; os[14] = xr_full; os[15] = xr_nfull;
-#endif
-#ifdef SGPU_PROF_STAGE1
-      os[13] = xs0; os[14] = xs1; os[15] = xs2;
-#endif
     }
 #undef TICK
   }
