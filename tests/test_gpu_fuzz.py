@@ -79,3 +79,48 @@ def test_differential(seed, monkeypatch):
                 assert np.array_equal(gs[i, :n].view(np.uint32), cs[i, :n].view(np.uint32)), (ctx, i)
     finally:
         orc.knn_attach(None, 0)
+
+
+def test_long_summary_rows_and_long_queries():
+    """Stage 1 edge cases: summary rows of thousands of entries (more than 64 chunks of 64 per
+    wavefront, so the chunk-descriptor block is refilled), one-block lists, and queries of more than
+    64 components (more than one block of rows). Dots and searches bit-exact against the oracle."""
+    rng = np.random.default_rng(77)
+    dim, n_docs = 3000, 12000
+    vecs = []
+    for d in range(n_docs):   # three ubiquitous light components + a few heavy rare ones: ~9000 one-document blocks
+        extra = rng.choice(np.arange(3, dim), int(rng.integers(2, 7)), replace=False)
+        c = np.sort(np.concatenate([[0, 1, 2], extra])).astype(np.uint32)
+        v = np.where(c < 3, rng.uniform(0.01, 0.05, len(c)), rng.uniform(1.0, 3.0, len(c))).astype(np.float32)
+        vecs.append((c, v))
+    off, comps, vals = orc.csr(vecs)
+    cfg = BuildConfig.defaults(n_postings=n_docs, centroid_fraction=0.75, summary_energy=1.0, max_fraction=1.0,
+                               min_cluster_size=0, doc_cut=10)
+    ix = _native.NativeIndex.build(2, dim, off, comps, vals, cfg).upload(0)
+    a = orc.desc_arrays(ix.desc)
+    nb0 = int(a["list_block_start"][1] - a["list_block_start"][0])
+    rows0 = a["row_ptr"][int(a["list_row_start"][0]): int(a["list_row_start"][1]) + 1]
+    assert nb0 > 5000 and int(np.diff(rows0).max()) > 64 * 64 * 2, (nb0, np.diff(rows0).max())
+    qs = []
+    for n in (3, 10, 70, 150):
+        c = np.sort(rng.choice(dim, n, replace=False)).astype(np.uint32)
+        if 0 not in c:
+            c[0] = 0
+            c = np.unique(c)
+        v = (rng.exponential(0.5, len(c)) + 0.01).astype(np.float32)
+        v[0] = 9.0   # list 0 (the long rows) is walked first
+        qs.append((c, v))
+    for c, v in qs:
+        for lst in (0, 1, 2, 5):
+            g = ix.summary_distances(lst, c, v)
+            o = orc.summary_distances(ix.desc, lst, c, v)
+            assert np.array_equal(g.view(np.uint32), o.view(np.uint32)), (lst, len(c))
+    q = orc.csr(qs)
+    for k, qcut, hf in ((10, 1, 1.0), (100, 1, 0.7), (5, 1, 0.0)):
+        gs, gi, gn = ix.batch_search(*q, k, qcut, hf, False)
+        cs, ci, cn, _, _, _ = orc.batch_search(ix.desc, *q, k, qcut, hf, False)
+        assert np.array_equal(gn, cn)
+        for i in range(len(gn)):
+            n = int(gn[i])
+            assert np.array_equal(gi[i, :n], ci[i, :n]), (k, qcut, hf, i)
+            assert np.array_equal(gs[i, :n].view(np.uint32), cs[i, :n].view(np.uint32)), (k, qcut, hf, i)
