@@ -59,10 +59,6 @@ for i, n in enumerate(NAMES):
     if i == 10:
         continue
     print("  %-22s %9.0f cyc  %5.1f%%" % (n, cyc[:, i].mean(), 100 * cyc[:, i].sum() / tot.sum()))
-if os.environ.get("SGPU_PROF_KIND") == "stage1":
-    print("stage 1 detail (list 0): descriptors %.0f cyc, prologue %.0f cyc, loop %.0f cyc" % (st[:, 21].mean() * 16, st[:, 22].mean() * 16, st[:, 23].mean() * 16))
-elif st[:, 21:24].sum() > 0:
-    print("replay detail: candidate-path %.0f cyc, full-path %.0f cyc in %.2f rounds/query" % (st[:, 21].mean() * 16, st[:, 22].mean() * 16, st[:, 23].mean()))
 print("work/query: blocks %.0f rows %.0f entries %.0f | scored blocks %.0f postings %.0f docs %.0f (spec %.0f)" % tuple(
     st[:, i].mean() for i in (0, 1, 2, 3, 4, 5, 7)))
 # per-slot busy time: queries per slot and sum
