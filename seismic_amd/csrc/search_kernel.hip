@@ -74,6 +74,19 @@ SGPU_DEV int32_t total_key_dev(float f) {  // Rust f32::total_cmp order
   return b;
 }
 
+// q * (float)half(packed, hi) with ONE rounding, the product the reference computes after widening
+// the stored f16: v_fma_mix_f32 widens the selected half on the fly and adds -0.0, which leaves the
+// rounded product untouched, signed zeros and denormals included (tools/ubench/fma_mix_check.hip:
+// bit-identical to v_cvt_f32_f16 + v_mul_f32). One instruction instead of convert (+ shift) + multiply.
+SGPU_DEV float mul_f32_f16(float q, uint32_t packed, int hi) {
+  float r;
+  if (hi)
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(q), "v"(packed), "s"(0x80000000u));
+  else
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=v"(r) : "v"(q), "v"(packed), "s"(0x80000000u));
+  return r;
+}
+
 SGPU_DEV float half_bits_to_float(uint32_t h) {   // exact binary16 -> binary32 (v_cvt_f32_f16)
   const unsigned short b = (unsigned short)h;
   _Float16 x;
@@ -631,10 +644,7 @@ SGPU_DEV float accumulate_chunk(const Lds& s, const DocChunk<CT>& d, uint32_t e0
     for (int i = 0; i < 8; ++i) qv[i] = s.q_val[r[i]];
   }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float dv = half_bits_to_float((v[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
-    acc = __fadd_rn(acc, __fmul_rn(qv[i], dv));
-  }
+  for (int i = 0; i < 8; ++i) acc = __fadd_rn(acc, mul_f32_f16(qv[i], v[i >> 1], i & 1));
   return acc;
 }
 
