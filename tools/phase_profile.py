@@ -82,4 +82,6 @@ for i in range(a.queries):
     v = qv[q_off[i]:q_off[i + 1]]
     top = c[np.argsort(-v, kind="stable")[: a.query_cut]]
     proxy[i] = npost[top].sum()
+if os.environ.get("SGPU_PROFILE_DUMP"):
+    np.save(os.environ["SGPU_PROFILE_DUMP"], np.column_stack([tot, proxy, st[:, 7], st[:, 2], st[:, 0]]))
 print("corr(proxy, cycles) = %.3f, corr(docs, cycles) = %.3f" % (np.corrcoef(proxy, tot)[0, 1], np.corrcoef(docs_q, tot)[0, 1]))
