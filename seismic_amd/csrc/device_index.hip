@@ -546,7 +546,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   a->p.items_max = items_max;
   a->p.items_init = std::min<uint32_t>(items_max, env_u32("SGPU_ITEMS_INIT", 128));
   a->p.items_min = std::min<uint32_t>(a->p.items_init, env_u32("SGPU_ITEMS_MIN", 64));
-  a->p.rblocks_max = env_u32("SGPU_RBLOCKS", 8);
+  a->p.rblocks_max = std::min<uint32_t>(32, std::max<uint32_t>(1, env_u32("SGPU_RBLOCKS", 8)));   // one mask bit per block
   a->p.target_list = mode == MODE_DOTS ? sp.query_cut : 0;
   a->ix = d->view;
   a->comp_width = d->comp_width;

@@ -1133,15 +1133,16 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
           uint32_t R = (remaining + NT - 1) / NT;
           if (R > p.rblocks_max) R = p.rblocks_max;
           const uint32_t scan_end = (pos + R * NT < nb) ? pos + R * NT : nb;
-          uint32_t my_live = 0;
+          uint32_t live_mask = 0;   // bit r: block my0 + r passes the skip test (R <= 32)
           const uint32_t my0 = pos + threadIdx.x * R;
           for (uint32_t r = 0; r < R; ++r) {
             const uint32_t idx = my0 + r;
             if (idx < scan_end) {
               const uint32_t b = sorted ? (uint32_t)s.order[idx] : idx;
-              my_live += !(full && dots[b] < cut);
+              live_mask |= (uint32_t)!(full && dots[b] < cut) << r;
             }
           }
+          const uint32_t my_live = (uint32_t)__popc(live_mask);
           uint32_t n_live_total;
           const uint32_t live_incl = wg_inclusive_scan<NT>(my_live, s.part, &n_live_total);
           if (n_live_total == 0) {
@@ -1152,13 +1153,8 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
           }
           {
             uint32_t o = live_incl - my_live;
-            for (uint32_t r = 0; r < R && o < NT; ++r) {
-              const uint32_t idx = my0 + r;
-              if (idx < scan_end) {
-                const uint32_t b = sorted ? (uint32_t)s.order[idx] : idx;
-                if (!(full && dots[b] < cut)) cb.live_pos[o++] = (uint16_t)idx;
-              }
-            }
+            for (uint32_t m = live_mask; m && o < NT; m &= m - 1)
+              cb.live_pos[o++] = (uint16_t)(my0 + (uint32_t)__ffs((int)m) - 1u);
           }
           const uint32_t n_live = n_live_total < NT ? n_live_total : NT;
           __syncthreads();
