@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """bench.py — Seismic search hot path on MI355X: queries/sec at fixed recall@10.
 
-A "step" is ONE pass of the search kernel over one batch of queries that is
-already resident in HBM (index resident too). Workload (BASELINE.json configs[1]):
-synthetic SPLADE-shape, 1M docs x 30K vocab x ~120 nnz/doc, 1K queries, k=10,
-index params of best_configs/msmarco-v1/splade-v3/mem_budget_2.0/recall_95.toml
-(n_postings=2000, centroid_fraction=0.2, summary_energy=0.5, max_fraction=6,
-min_cluster_size=2, doc_cut=15), query params query_cut=4, heap_factor=1.0,
-first_sorted=false.
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): MS MARCO passage /
+SPLADE-v3 shape, 8.8M docs x 30K vocab x ~120 nnz/doc, synthetic (SURVEY.md 8d generator), index
+parameters of best_configs/msmarco-v1/splade-v3/mem_budget_2.0/recall_95.toml (n_postings=2000,
+centroid_fraction=0.2, summary_energy=0.5, max_fraction=6, min_cluster_size=2, doc_cut=15), query
+parameters query_cut=4, heap_factor=1.0, first_sorted=false, k=10.
+
+A "step" is ONE pass of the search kernel over one batch of 10 000 queries (BASELINE configs[3]'s
+batch) that is resident in HBM when the timed region starts, index resident too. Every step of a
+run (warm-up included) searches a batch no other step has seen: nothing is cached between steps,
+and the per-batch launch plan (longest-expected-first order) is computed inside the timed region.
 
   python bench.py --gpus N --steps K --warmup W
-N>1 is launched by the driver through torch.distributed.run (one rank per GPU):
-the index is replicated, every rank searches its own batch of --queries queries
-(weak scaling, no collective on the data path); value = total queries / max-over-ranks time.
+N>1 is launched through torch.distributed.run, one rank per GPU, index replicated in every GPU's
+HBM, no collective on the data path:
+  --scaling strong (default for N>1; BASELINE configs[3]): each 10 000-query batch is cut into N
+      contiguous shards, one per GPU; `value` = 10 000 x K / max-over-ranks time.
+  --scaling weak: every GPU searches its own 10 000-query batches.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+Real data instead of synthetic: --documents documents.bin --queries-file queries.bin
+[--groundtruth groundtruth.tsv] [--results-tsv out.tsv] (Seismic's inner format and the TSV of
+perf_inverted_index).
+
+Prints ONE JSON line on rank 0 (fields: DESIGN.md "Measurement").
 """
 import argparse
 import json
 import os
 import sys
 import tempfile
+import threading
 import time
 
 import numpy as np
@@ -30,21 +40,25 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 measured achievable
+METRIC = "queries/sec + mean latency (µs) at fixed recall@10 vs exact, SPLADE-v3 MSMARCO"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--docs", type=int, default=1_000_000)
+    ap.add_argument("--docs", type=int, default=8_800_000)
     ap.add_argument("--dim", type=int, default=30_000)
-    ap.add_argument("--queries", type=int, default=1000)
+    ap.add_argument("--queries", type=int, default=10_000, help="queries per step (one batch)")
+    ap.add_argument("--batches", type=int, default=0,
+                    help="distinct resident batches (0 = one per step incl. warm-up, at most 64)")
+    ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--query-cut", type=int, default=4)
     ap.add_argument("--heap-factor", type=float, default=1.0)
@@ -55,28 +69,46 @@ def main():
     ap.add_argument("--max-fraction", type=float, default=6.0)
     ap.add_argument("--min-cluster-size", type=int, default=2)
     ap.add_argument("--comp-width", type=int, default=2, choices=[2, 4])
+    ap.add_argument("--sample", type=int, default=1000,
+                    help="queries of the first timed batch used for recall, the oracle identity check and cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-recall", action="store_true", help="skip recall@k vs exact")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget per mode")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end sgpu_batch_search measurement")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
     ap.add_argument("--index-cache", default=os.environ.get("SGPU_INDEX_CACHE", ""))
     ap.add_argument("--traffic-bytes", type=float, default=None,
                     help="HBM bytes per launch measured by a separate rocprofv3 --pmc pass (roofline.traffic)")
-    args = ap.parse_args()
+    # real data (Seismic's inner binary format / perf_inverted_index TSV)
+    ap.add_argument("--documents", default="", help="documents.bin (inner format) instead of synthetic documents")
+    ap.add_argument("--queries-file", default="", help="queries.bin (inner format) instead of synthetic queries")
+    ap.add_argument("--groundtruth", default="", help="groundtruth.tsv: accuracy as scripts/run_experiments.py computes it")
+    ap.add_argument("--results-tsv", default="", help="write query_idx\\tdoc_id\\trank\\tscore of the first batch here")
+    return ap.parse_args()
 
+
+def workload_key(args, world, scaling):
+    src = "docs=%d dim=%d" % (args.docs, args.dim) if not args.documents else "documents=%s" % os.path.basename(args.documents)
+    return "%s queries=%d k=%d query_cut=%d heap_factor=%s first_sorted=%d cw=%d np=%d cf=%g se=%g mf=%g" % (
+        src, args.queries, args.k, args.query_cut, args.heap_factor, args.first_sorted, args.comp_width,
+        args.n_postings, args.centroid_fraction, args.summary_energy, args.max_fraction)
+
+
+def main():
+    args = parse_args()
     import torch
     import torch.distributed as dist
 
     from seismic_amd import _native
     from seismic_amd._abi import BuildConfig
+    from seismic_amd.sharding import shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus))
     if not torch.cuda.is_available() or _native.device_count() < 1:
         raise SystemExit("no GPU visible: the search path has no CPU fallback")
     # SGPU_BENCH_BACKEND=gloo + SGPU_BENCH_ONE_DEVICE=1 lets the N>1 control flow be exercised on a
@@ -91,25 +123,32 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---------------- data + index (rank 0 builds, the others load the file) ----------------
+    n_batches = args.batches or min(args.steps + args.warmup, 64)
+    n_batches = max(1, n_batches)
+
+    # ---------------- data + index: rank 0 prepares, the others load its files ----------------
     cfg = BuildConfig.defaults(n_postings=args.n_postings, centroid_fraction=args.centroid_fraction,
                                summary_energy=args.summary_energy, max_fraction=args.max_fraction,
                                min_cluster_size=args.min_cluster_size, doc_cut=15)
-    tag = "sgpu_%d_%d_cw%d_np%d_cf%g_se%g_mf%g_mc%d.idx" % (
-        args.docs, args.dim, args.comp_width, args.n_postings, args.centroid_fraction, args.summary_energy,
+    src_tag = ("%d_%d" % (args.docs, args.dim)) if not args.documents else \
+        ("file_%s_%d" % (os.path.basename(args.documents), os.path.getsize(args.documents)))
+    tag = "sgpu2_%s_cw%d_np%d_cf%g_se%g_mf%g_mc%d" % (
+        src_tag, args.comp_width, args.n_postings, args.centroid_fraction, args.summary_energy,
         args.max_fraction, args.min_cluster_size)
     cache_dir = args.index_cache or tempfile.gettempdir()
-    path = os.path.join(cache_dir, tag)
-    t0 = time.time()
-    docs = _native.synth(args.docs, args.dim, 42, 0)
-    t_gen = time.time() - t0
-    t_build = 0.0
+    path = os.path.join(cache_dir, tag + ".idx")
+    qpath = os.path.join(cache_dir, tag + "_q%d_b%d_w%d_%s.bin" % (args.queries, n_batches, world, scaling))
+    t_gen = t_build = 0.0
+    # query sets: strong scaling = the same n_batches global batches on every rank (each takes its
+    # shard); weak scaling = n_batches batches per rank
+    n_sets = n_batches * (world if scaling == "weak" else 1)
     if rank == 0:
         index = None
         if os.path.exists(path):
@@ -117,100 +156,154 @@ def main():
                 index = _native.NativeIndex.load(path)
             except _native.SeismicHipError:   # a stale / truncated file from an interrupted run
                 index = None
+        need_docs = index is None or not args.queries_file
+        docs = None
+        if need_docs:
+            t0 = time.time()
+            docs = _native.read_inner_format(args.documents) if args.documents else _native.synth(args.docs, args.dim, 42, 0)
+            t_gen = time.time() - t0
         if index is None:
             t0 = time.time()
-            index = _native.NativeIndex.build(args.comp_width, args.dim, *docs, cfg)
+            dim = args.dim if not args.documents else max(args.dim, int(docs[1].max()) + 1)
+            index = _native.NativeIndex.build(args.comp_width, dim, *docs, cfg)
             t_build = time.time() - t0
             if world > 1 or args.index_cache:
                 tmp = "%s.tmp.%d" % (path, os.getpid())
                 index.save(tmp)
                 os.replace(tmp, path)     # the other ranks only ever see a complete file
-        log("[bench] docs generated in %.1fs, index built in %.1fs" % (t_gen, t_build))
+        if args.queries_file:
+            allq = _native.read_inner_format(args.queries_file)
+        else:
+            allq = _native.synth(args.queries * n_sets, int(index.desc.dim), 43, 1, docs)
+        if world > 1:
+            tmp = "%s.tmp.%d" % (qpath, os.getpid())
+            _native.write_inner_format(tmp, *allq)
+            os.replace(tmp, qpath)
+        del docs
+        log("[bench] documents ready in %.1fs, index built in %.1fs" % (t_gen, t_build))
     barrier()
     if rank != 0:
         index = _native.NativeIndex.load(path)
+        allq = _native.read_inner_format(qpath)
     t0 = time.time()
     index.upload(local_rank)
     t_up = time.time() - t0
     d = index.desc
-    queries = _native.synth(args.queries, args.dim, 43 + 1000 * rank, 1, docs)
-    q_off, q_comp, q_val = queries
-    batch = _native.DeviceBatch(index, q_off, q_comp, q_val, args.k)
+    a_off, a_comp, a_val = allq
+    n_all = len(a_off) - 1
+    if args.queries_file:   # a real query file is one batch (repeated if more steps are asked for)
+        args.queries = n_all
+        n_batches = 1
 
-    def step(sync=False):
-        return batch.run(args.k, args.query_cut, args.heap_factor, bool(args.first_sorted), sync=sync)
+    def batch_csr(i):
+        """CSR of this rank's part of batch i."""
+        if scaling == "weak":
+            lo = (rank * n_batches + i) * args.queries if not args.queries_file else 0
+            hi = lo + args.queries
+        else:
+            s, e = shard_bounds(args.queries, world, rank)
+            lo, hi = i * args.queries + s, i * args.queries + e
+        o0, o1 = int(a_off[lo]), int(a_off[hi])
+        return (a_off[lo:hi + 1] - a_off[lo]).astype(np.uint64), a_comp[o0:o1], a_val[o0:o1]
+
+    host_batches = [batch_csr(i) for i in range(n_batches)]
+    batches = [_native.DeviceBatch(index, *hb, args.k) for hb in host_batches]
+    my_q = len(host_batches[0][0]) - 1
+    total_q_per_step = args.queries * (world if scaling == "weak" else 1)
+    srt = bool(args.first_sorted)
+
+    def step(i):
+        batches[i % n_batches].run(args.k, args.query_cut, args.heap_factor, srt, sync=False)
 
     # ---------------- timed region ----------------
-    for _ in range(args.warmup):
-        step()
-    batch.sync()
+    for i in range(args.warmup):
+        step(i)
+    batches[0].sync()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    batch.sync_stats = batch.sync()   # waits for the K launches; mean kernel duration from HIP events
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync_stats = batches[0].sync()   # waits for the K launches; mean kernel duration from HIP events
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(batch.sync_stats.kernel_ms)
+    kernel_ms = float(sync_stats.kernel_ms)
+    timed_ids = sorted({(args.warmup + i) % n_batches for i in range(args.steps)})
 
     # ---------------- accounting (outside the timed region) ----------------
-    gsc, gid, gn = batch.fetch(args.k)
-    # one extra, untimed pass with the visited set materialised (sgpu_batch_run_counted): identical
-    # results, and work counters that exclude re-encountered documents exactly as the reference does
-    batch.run_counted(args.k, args.query_cut, args.heap_factor, bool(args.first_sorted))
-    csc, cid, cn = batch.fetch(args.k)
-    counted_identical = bool(np.array_equal(cn, gn) and np.array_equal(cid, gid)
-                             and np.array_equal(csc.view(np.uint32), gsc.view(np.uint32)))
-    algo_bytes, counters = batch.algorithmic_bytes(args.k, args.comp_width)
-    total_q = args.queries * world
+    # every timed batch gets one extra pass with the visited set materialised (sgpu_batch_run_counted):
+    # identical results, and work counters that exclude re-encountered documents exactly as the
+    # reference does -> algorithmic bytes of each launch
+    algo, counted_identical, results = [], True, {}
+    agg = np.zeros(8, np.float64)
+    for bi in timed_ids:
+        b = batches[bi]
+        gsc, gid, gn = b.fetch(args.k)
+        b.run_counted(args.k, args.query_cut, args.heap_factor, srt)
+        csc, cid, cn = b.fetch(args.k)
+        counted_identical &= bool(np.array_equal(cn, gn) and np.array_equal(cid, gid)
+                                  and np.array_equal(csc.view(np.uint32), gsc.view(np.uint32)))
+        ab, counters = b.algorithmic_bytes(args.k, args.comp_width)
+        algo.append(ab)
+        agg += counters[:, :8].sum(axis=0)
+        results[bi] = (gsc, gid, gn)
+    nq_counted = max(1, my_q * len(timed_ids))
+    algo_bytes = float(np.mean(algo))
     ms_per_step = elapsed * 1e3 / args.steps
-    qps = total_q * args.steps / elapsed
+    qps = total_q_per_step * args.steps / elapsed
     achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    # roofline.traffic: HBM bytes per launch from a SEPARATE rocprofv3 --pmc pass (counters cannot be
-    # collected from inside this process); taken from --traffic-bytes or profiles/pmc_traffic.json
-    # when that measurement was made on this very workload, else null.
+    key = workload_key(args, world, scaling)
     traffic_bytes = args.traffic_bytes
-    if traffic_bytes is None:
+    if traffic_bytes is None and world == 1:
+        # roofline.traffic: HBM bytes per launch from SEPARATE rocprofv3 --pmc passes of this command
+        # (counters cannot be collected from inside this process), recorded in profiles/pmc_traffic.json
+        # under the workload they were measured on; null for any other workload.
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            key = "docs=%d dim=%d queries=%d k=%d query_cut=%d heap_factor=%s first_sorted=%d" % (
-                args.docs, args.dim, args.queries, args.k, args.query_cut, args.heap_factor, args.first_sorted)
-            if pm.get("workload") == key:
-                traffic_bytes = float(pm["traffic_bytes"])
+            ent = pm.get("workloads", {}).get(key)
+            if ent:
+                traffic_bytes = float(ent["traffic_bytes"])
         except (OSError, ValueError, KeyError):
             pass
+    first = timed_ids[0]
+    gsc, gid, gn = results[first]
     out = {
-        "metric": "queries/sec + mean latency (\u00b5s) at fixed recall@10 vs exact, SPLADE-v3 MSMARCO",
+        "metric": METRIC,
         "value": qps,
         "unit": "queries/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
-        "mean_latency_us_per_query_in_batch": ms_per_step * 1e3 / args.queries,
+        "amortized_us_per_query": ms_per_step * 1e3 / total_q_per_step,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not args.documents else "file",
         "config": {
-            "workload": "Synthetic SPLADE-shape: %d docs, %d vocab, ~120 nnz/doc, %d queries/GPU, k=%d, 1xMI355X per rank"
-                        % (args.docs, args.dim, args.queries, args.k),
+            "workload": ("MSMARCO-passage SPLADE-v3 shape (synthetic): %d docs, %d vocab, ~120 nnz/doc, best_configs params, "
+                         "k=%d, %d-query batch per step%s, %d distinct batches, %dxMI355X"
+                         % (int(d.n_docs), int(d.dim), args.k, args.queries,
+                            (" sharded over %d GPUs" % world) if (world > 1 and scaling == "strong") else
+                            (" per GPU" if world > 1 else ""), n_batches, world)),
+            "workload_key": key,
             "index": {"n_postings": args.n_postings, "centroid_fraction": args.centroid_fraction,
                       "summary_energy": args.summary_energy, "max_fraction": args.max_fraction,
                       "min_cluster_size": args.min_cluster_size, "doc_cut": 15,
                       "hbm_bytes": index.device_bytes(), "n_blocks": int(d.n_blocks),
                       "n_postings_kept": int(d.n_postings), "summary_entries": int(d.n_entries)},
             "query": {"k": args.k, "query_cut": args.query_cut, "heap_factor": args.heap_factor,
-                      "first_sorted": bool(args.first_sorted)},
+                      "first_sorted": srt},
             "storage": "f16 document values, u%d components, u8-quantised block summaries" % (8 * args.comp_width),
-            "parallelism": "index replicated, %d query batch(es) of %d, no collective" % (world, args.queries),
-            "launch": {"grid": int(batch.sync_stats.grid), "block": int(batch.sync_stats.block),
-                       "lds_bytes": int(batch.sync_stats.lds_bytes)},
+            "parallelism": "index replicated, %s, no collective" % (
+                ("each batch of %d cut into %d contiguous shards" % (args.queries, world)) if scaling == "strong" and world > 1
+                else ("%d batch(es) of %d per step" % (world, args.queries))),
+            "launch": {"grid": int(sync_stats.grid), "block": int(sync_stats.block),
+                       "lds_bytes": int(sync_stats.lds_bytes), "queries_per_launch": my_q},
         },
         "roofline": {
             "bound": "hbm",
@@ -222,90 +315,141 @@ def main():
             "kernel": "seismic_search_kernel",
             "kernel_ms": kernel_ms,
             "algorithmic_bytes_per_launch": algo_bytes,
-            "bytes_per_query": algo_bytes / max(args.queries, 1),
-            "docs_scored_per_query": float(counters[:, 5].mean()) if len(counters) else 0.0,
-            "docs_scored_speculatively_per_query": float(counters[:, 7].mean()) if len(counters) else 0.0,
-            "summary_entries_per_query": float(counters[:, 2].mean()) if len(counters) else 0.0,
+            "bytes_per_query": algo_bytes / max(my_q, 1),
+            "docs_scored_per_query": agg[5] / nq_counted,
+            "docs_scored_speculatively_per_query": agg[7] / nq_counted,
+            "summary_entries_per_query": agg[2] / nq_counted,
             "counted_pass_identical": counted_identical,
+            "launches_accounted": len(timed_ids),
         },
         "timing_s": {"generate": t_gen, "build": t_build, "upload": t_up},
     }
+
+    # ---- N>1, strong scaling: the sharded batch must be the 1-GPU answer, in input order ----
+    if world > 1 and scaling == "strong":
+        from seismic_amd.sharding import gather_rows
+        full = gather_rows(gsc, gid, gn, args.queries)
+        if rank == 0:
+            lo, hi = first * args.queries, (first + 1) * args.queries
+            o0, o1 = int(a_off[lo]), int(a_off[hi])
+            ref = index.batch_search((a_off[lo:hi + 1] - a_off[lo]).astype(np.uint64), a_comp[o0:o1], a_val[o0:o1],
+                                     args.k, args.query_cut, args.heap_factor, srt)
+            out["sharded_identical_to_single_gpu"] = bool(
+                np.array_equal(ref[2], full[2]) and np.array_equal(ref[1], full[1])
+                and np.array_equal(ref[0].view(np.uint32), full[0].view(np.uint32)))
+
+    if rank == 0 and args.results_tsv:
+        _native.write_results_tsv(args.results_tsv, gsc, gid, gn)
+    if rank == 0 and args.groundtruth:
+        from seismic_amd.index import accuracy, read_results_tsv
+        res = {q: [int(x) for x in gid[q, :gn[q]]] for q in range(len(gn))}
+        out["accuracy_vs_groundtruth"] = accuracy(res, read_results_tsv(args.groundtruth))
+
+    ns = min(args.sample, my_q)
+    s_off, s_comp, s_val = host_batches[first]
+    s_off = s_off[:ns + 1].copy()
+    s_comp, s_val = s_comp[:int(s_off[ns])], s_val[:int(s_off[ns])]
+
+    if rank == 0 and not args.no_e2e:
+        # End to end through the drop-in entry point, host buffers in and out (sgpu_batch_search:
+        # validation + H2D of the queries + launch plan + kernel + D2H of the results), on the timed
+        # batches: once from one host thread, once from two threads on the same index (two lanes).
+        hb = [host_batches[i] for i in timed_ids]
+        index.batch_search(*hb[0], args.k, args.query_cut, args.heap_factor, srt)   # grows the lane's batch
+        t0 = time.perf_counter()
+        for h in hb:
+            index.batch_search(*h, args.k, args.query_cut, args.heap_factor, srt)
+        e1 = time.perf_counter() - t0
+
+        def worker(part):
+            for h in part:
+                index.batch_search(*h, args.k, args.query_cut, args.heap_factor, srt)
+        worker(hb[:2])
+        th = [threading.Thread(target=worker, args=(hb[i::2],)) for i in range(2)]
+        t0 = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        e2 = time.perf_counter() - t0
+        out["end_to_end"] = {
+            "entry_point": "sgpu_batch_search (host buffers in and out)",
+            "queries_per_call": my_q, "calls": len(hb),
+            "qps_one_host_thread": my_q * len(hb) / e1, "ms_per_call": e1 * 1e3 / len(hb),
+            "qps_two_host_threads": my_q * len(hb) / e2,
+        }
+
     if rank == 0 and not args.no_latency:
         # mean latency of batch-1 searches (the reference's AQT: one query at a time,
-        # src/bin/perf_inverted_index.rs:184-216): resident single-query batches, one synchronous
-        # kernel pass each; wall time around launch + completion.
-        nlat = min(200, args.queries)
-        singles = [_native.DeviceBatch(index, np.array([0, q_off[i + 1] - q_off[i]], np.uint64),
-                                       q_comp[q_off[i]:q_off[i + 1]], q_val[q_off[i]:q_off[i + 1]], args.k)
-                   for i in range(nlat)]
-        for sb in singles[:10]:
-            sb.run(args.k, args.query_cut, args.heap_factor, bool(args.first_sorted), sync=True)
+        # src/bin/perf_inverted_index.rs:184-216): sgpu_search per query, host buffers in and out
+        nlat = min(200, ns)
+        qs = [(s_comp[int(s_off[i]):int(s_off[i + 1])], s_val[int(s_off[i]):int(s_off[i + 1])]) for i in range(nlat)]
+        for c, v in qs[:10]:
+            index.search(c, v, args.k, args.query_cut, args.heap_factor, srt)
         t0 = time.perf_counter()
+        for c, v in qs:
+            index.search(c, v, args.k, args.query_cut, args.heap_factor, srt)
+        out["mean_latency_us_single_query"] = (time.perf_counter() - t0) * 1e6 / max(nlat, 1)
+        singles = [_native.DeviceBatch(index, np.array([0, len(c)], np.uint64), c, v, args.k) for c, v in qs[:50]]
         kms = 0.0
         for sb in singles:
-            kms += sb.run(args.k, args.query_cut, args.heap_factor, bool(args.first_sorted), sync=True).kernel_ms
-        out["mean_latency_us_single_query"] = (time.perf_counter() - t0) * 1e6 / nlat
-        out["mean_kernel_us_single_query"] = kms * 1e3 / nlat
+            kms += sb.run(args.k, args.query_cut, args.heap_factor, srt, sync=True).kernel_ms
+        out["mean_kernel_us_single_query"] = kms * 1e3 / max(len(singles), 1)
         del singles
+
     if rank == 0 and not args.no_recall:
         t0 = time.time()
-        es, ei, en = index.exact_search(q_off, q_comp, q_val, args.k)
+        es, ei, en = index.exact_search(s_off, s_comp, s_val, args.k)
         hits = 0
-        for i in range(args.queries):
+        for i in range(ns):
             hits += len(set(gid[i, :gn[i]].tolist()) & set(ei[i, :en[i]].tolist()))
-        out["recall_at_k"] = hits / float(args.queries * args.k)
+        out["recall_at_k"] = hits / float(max(ns, 1) * args.k)
+        out["recall_sample_queries"] = ns
         out["timing_s"]["exact_ground_truth"] = time.time() - t0
+
     if rank == 0 and world == 1 and not args.no_cpu:
-        # ---- cpu_baseline: the CPU oracle (a port; the Rust reference cannot be built here),
-        # timed on this box's host cores on the same index + the same query batch.
+        # ---- cpu_baseline: the CPU oracle (a port; the Rust reference cannot be built here), timed
+        # on this box's host cores on the same index and a bounded sample of the same queries.
         import orc
         ncores = os.cpu_count() or 1
-        # single thread: the sequential loop of perf_inverted_index (bounded sample)
-        osc, oid, on, ost, secs1, _ = orc.batch_search(d, q_off, q_comp, q_val, args.k, args.query_cut,
-                                                       args.heap_factor, bool(args.first_sorted), num_threads=1)
-        identical = bool(np.array_equal(on, gn) and np.array_equal(oid, gid)
-                         and np.array_equal(osc.view(np.uint32), gsc.view(np.uint32)))
-        runs1 = 1
-        t_total = secs1
-        while t_total < args.cpu_seconds / 2 and runs1 < 64:
-            t_total += orc.batch_search(d, q_off, q_comp, q_val, args.k, args.query_cut, args.heap_factor,
-                                        bool(args.first_sorted), num_threads=1)[4]
-            runs1 += 1
-        qps1 = runs1 * args.queries / t_total
-        # many cores: one query per task (rayon global pool in batch_search). The best thread count
-        # is searched (random 480-byte gathers stop scaling long before 256 hardware threads).
+        q = (s_off, s_comp, s_val)
+        osc, oid, on, ost, secs1, _ = orc.batch_search(d, *q, args.k, args.query_cut, args.heap_factor, srt, num_threads=1)
+        identical = bool(np.array_equal(on, gn[:ns]) and np.array_equal(oid, gid[:ns])
+                         and np.array_equal(osc.view(np.uint32), gsc[:ns].view(np.uint32)))
+        qps1 = ns / secs1
+        # many cores: one query per task (the reference's rayon pool). Thread counts up to every
+        # hardware thread are tried (random 480-byte gathers stop scaling long before that); each is
+        # timed on its second and third pass, the best one is then run for the rest of the budget.
         sweep = {}
-        cands = sorted({c for c in (0, ncores // 2, ncores // 4, 64, 32, 16) if c == 0 or 2 <= c <= ncores})
-        for nt in cands:
+        t_sweep = time.time()
+        for nt in sorted({c for c in (ncores, ncores // 2, ncores // 4, 64, 32, 16) if 2 <= c <= ncores}):
             best = 0.0
             for rep in range(3):
-                r = orc.batch_search(d, q_off, q_comp, q_val, args.k, args.query_cut, args.heap_factor,
-                                     bool(args.first_sorted), num_threads=nt)
+                r = orc.batch_search(d, *q, args.k, args.query_cut, args.heap_factor, srt, num_threads=nt)
                 if rep:
-                    best = max(best, args.queries / r[4])
+                    best = max(best, ns / r[4])
             sweep[int(r[5])] = best
+            if time.time() - t_sweep > args.cpu_seconds / 2:
+                break
         used = max(sweep, key=sweep.get)
         runs_n, t_n = 0, 0.0
-        while (t_n < args.cpu_seconds / 2 and runs_n < 512) or runs_n < 2:
-            r = orc.batch_search(d, q_off, q_comp, q_val, args.k, args.query_cut, args.heap_factor,
-                                 bool(args.first_sorted), num_threads=used)
-            if runs_n > 0:   # first run warms the per-thread scratch
-                t_n += r[4]
+        while t_n < args.cpu_seconds / 2 and runs_n < 512:
+            t_n += orc.batch_search(d, *q, args.k, args.query_cut, args.heap_factor, srt, num_threads=used)[4]
             runs_n += 1
-        qpsn = (runs_n - 1) * args.queries / t_n
+        qpsn = max(runs_n * ns / t_n, sweep[used])
         out["cpu_baseline"] = {
             "value": qpsn, "unit": "queries/s", "cores": int(used), "kind": "port",
-            "sample": "the same %d-query batch, %d passes on %d threads (OpenMP, one query per task); "
-                      "single thread: %d passes" % (args.queries, runs_n - 1, used, runs1),
+            "sample": "the first %d queries of the first timed batch: %d passes on %d OpenMP threads (one query "
+                      "per task) after a thread-count sweep; single thread: 1 pass" % (ns, runs_n, used),
             "single_thread_qps": qps1, "single_thread_us_per_query": 1e6 / qps1,
             "host_cores": ncores, "thread_sweep_qps": {str(k_): v_ for k_, v_ in sorted(sweep.items())},
             "gpu_results_identical_to_cpu": identical,
-            "algorithmic_bytes_cpu": int(ost["algo_bytes"]),
         }
         out["gpu_over_cpu_allcore"] = qps / qpsn if qpsn > 0 else None
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

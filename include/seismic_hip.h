@@ -156,9 +156,18 @@ sgpu_status sgpu_index_get_desc(const sgpu_index* idx, sgpu_index_desc* out);
  * Own flat SoA file format (the reference's wire format lives in un-vendored vectorium). */
 sgpu_status sgpu_index_save(const sgpu_index* idx, const char* path);
 sgpu_status sgpu_index_load(const char* path, sgpu_index** out);
-/* Copies the index into the HBM of HIP device `device` (one device per index;
- * multi-GPU = one process/index replica per GPU). */
+/* Copies the index into the HBM of HIP device `device` (replaces any earlier upload). */
 sgpu_status sgpu_index_upload(sgpu_index* idx, int32_t device);
+/* Replicates the index on n devices of this process (index replicated, queries
+ * sharded, no collective). Replica 0 is uploaded from the host; the others are copied from it GPU to
+ * GPU (hipMemcpyPeer: xGMI on an MI355X node). With more than one replica, sgpu_batch_search shards a
+ * batch contiguously over them, one host thread per device, and returns the rows in input order -
+ * what the reference's rayon loop over queries does on host cores (src/pylib/mod.rs:629-652, 1129-1145).
+ * A device id may be listed more than once (replicas sharing a device; used to test the path on a
+ * single-GPU box). Replaces any earlier upload. */
+sgpu_status sgpu_index_upload_many(sgpu_index* idx, const int32_t* device_ids, uint32_t n);
+/* Number of device replicas (0 before upload). */
+uint32_t sgpu_index_replicas(const sgpu_index* idx);
 /* kNN graph — replaces Knn::new / Knn::refine (src/inverted_index.rs:448-500, 551-593).
  * build: every document is searched as a query (k = nknn+1, query_cut 10, heap_factor 0.7) as
  * batches through the GPU kernel; needs an uploaded index. set/get: attach or read the flattened
@@ -184,7 +193,15 @@ sgpu_status sgpu_search(sgpu_index* idx, const uint32_t* comps, const float* val
 /* Replaces: SeismicIndexRaw.batch_search (src/pylib/mod.rs:1111-1146) and the
  * per-query loop of SeismicIndex.batch_search (src/pylib/mod.rs:629-652).
  * Queries in CSR form: query q = [q_off[q], q_off[q+1]). Results in input
- * order: out_scores/out_doc_ids are nq x k (row q padded past out_n[q]). */
+ * order: out_scores/out_doc_ids are nq x k (row q padded past out_n[q]).
+ * Thread safety: sgpu_search / sgpu_batch_search may be called from any number of host threads on one
+ * index (the reference's search takes &self and the index is Sync, src/index_traits.rs:106-113). Each
+ * call borrows one of a small pool of (stream, recycled device batch) lanes of the replica it runs on,
+ * so concurrent calls overlap on the device; a call allocates nothing once its lane's batch has grown
+ * to the call's size. Query-time semantics that differ from a panic in the reference: query_cut == 0
+ * walks no list and returns no result (k_largest_by(0), src/inverted_index.rs:187-190); any
+ * heap_factor is accepted, negative ones included (the skip test is evaluated exactly as
+ * src/posting_list.rs:130 does). */
 sgpu_status sgpu_batch_search(sgpu_index* idx, const uint64_t* q_off,
                               const uint32_t* comps, const float* vals, uint32_t nq,
                               const sgpu_search_params* params, float* out_scores,
@@ -195,6 +212,11 @@ sgpu_status sgpu_batch_search(sgpu_index* idx, const uint64_t* q_off,
 sgpu_status sgpu_batch_create(sgpu_index* idx, const uint64_t* q_off,
                               const uint32_t* comps, const float* vals, uint32_t nq,
                               uint32_t k_max, sgpu_batch** out);
+/* Same, on replica `replica` of an index uploaded with sgpu_index_upload_many (run / fetch / stats
+ * find the replica from the batch). */
+sgpu_status sgpu_batch_create_on(sgpu_index* idx, uint32_t replica, const uint64_t* q_off,
+                                 const uint32_t* comps, const float* vals, uint32_t nq,
+                                 uint32_t k_max, sgpu_batch** out);
 /* Enqueues one search pass over the batch on the library's stream. With
  * sync != 0 waits for it and fills *stats (may be NULL). */
 sgpu_status sgpu_batch_run(sgpu_index* idx, sgpu_batch* batch,
@@ -206,8 +228,8 @@ sgpu_status sgpu_batch_run(sgpu_index* idx, sgpu_batch* batch,
  * as the reference's FxHashSet does (src/inverted_index.rs:181-184). Used for accounting. */
 sgpu_status sgpu_batch_run_counted(sgpu_index* idx, sgpu_batch* batch,
                                    const sgpu_search_params* params, sgpu_launch_stats* stats);
-/* Blocks until all enqueued passes are done; *stats (may be NULL) gets the MEAN
- * kernel duration of the passes enqueued since the previous sync. */
+/* Blocks until all enqueued passes (of every replica) are done; *stats (may be NULL) gets the MEAN
+ * kernel duration of replica 0's passes enqueued since the previous sync. */
 sgpu_status sgpu_batch_sync(sgpu_index* idx, sgpu_launch_stats* stats);
 sgpu_status sgpu_batch_fetch(sgpu_index* idx, sgpu_batch* batch, uint32_t k,
                              float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n);
@@ -240,6 +262,20 @@ sgpu_status sgpu_exact_search(const sgpu_index* idx, const uint64_t* q_off,
                               const uint32_t* comps, const float* vals, uint32_t nq,
                               uint32_t k, uint32_t num_threads, float* out_scores,
                               uint64_t* out_doc_ids, uint32_t* out_n);
+/* Seismic's inner binary dataset format (documents.bin / queries.bin: written by the reference's
+ * scripts/convert_json_to_inner_format.py:10-27, read by vectorium's read_seismic_format at
+ * src/pylib/mod.rs:987,1127): u32 n_vecs; per vector u32 n, n x u32 components, n x f32 values.
+ * read: call with offsets == NULL to size (*n_vecs, *nnz receive the counts), then with buffers of
+ * n_vecs + 1 offsets and nnz components / values (*n_vecs, *nnz carry the capacities in). */
+sgpu_status sgpu_dataset_read(const char* path, uint64_t* n_vecs, uint64_t* nnz, uint64_t* offsets,
+                              uint32_t* comps, float* vals);
+sgpu_status sgpu_dataset_write(const char* path, uint64_t n_vecs, const uint64_t* offsets,
+                               const uint32_t* comps, const float* vals);
+/* Replaces: the result dump of perf_inverted_index (src/bin/perf_inverted_index.rs:223-235), the file
+ * scripts/run_experiments.py:287-309 compares with groundtruth.tsv:
+ * query_index \t doc_id \t rank (from 1) \t score, one line per result (rows of nq x k slabs). */
+sgpu_status sgpu_results_write_tsv(const char* path, uint32_t nq, uint32_t k, const float* scores,
+                                   const uint64_t* doc_ids, const uint32_t* n);
 /* Deterministic SPLADE-shaped synthetic data: writes a
  * CSR dataset into caller-provided buffers. Call with comps==NULL to size:
  * *out_nnz receives the number of entries. kind: 0 = documents, 1 = queries

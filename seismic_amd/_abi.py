@@ -2,7 +2,7 @@
 import ctypes as C
 
 SGPU_OK, SGPU_EINVAL, SGPU_EDEVICE, SGPU_ENOMEM, SGPU_EIO, SGPU_ELIMIT = range(6)
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)

@@ -48,6 +48,10 @@ def lib():
         L.sgpu_index_save.argtypes = [vp, C.c_char_p]
         L.sgpu_index_load.argtypes = [C.c_char_p, C.POINTER(vp)]
         L.sgpu_index_upload.argtypes = [vp, C.c_int32]
+        L.sgpu_index_upload_many.argtypes = [vp, vp, C.c_uint32]
+        L.sgpu_index_replicas.argtypes = [vp]
+        L.sgpu_index_replicas.restype = C.c_uint32
+        L.sgpu_batch_create_on.argtypes = [vp, C.c_uint32, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.sgpu_index_build_knn.argtypes = [vp, C.c_uint32]
         L.sgpu_index_set_knn.argtypes = [vp, vp, C.c_uint64, C.c_uint32]
         L.sgpu_index_get_knn.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
@@ -64,6 +68,9 @@ def lib():
         L.sgpu_exact_search.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
         L.sgpu_synth_generate.argtypes = [C.POINTER(SynthSpec), vp, vp, vp, C.c_uint64, vp, vp, vp,
                                           C.POINTER(C.c_uint64)]
+        L.sgpu_dataset_read.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp, vp, vp]
+        L.sgpu_dataset_write.argtypes = [C.c_char_p, C.c_uint64, vp, vp, vp]
+        L.sgpu_results_write_tsv.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, vp, vp, vp]
         if L.sgpu_abi_version() != ABI_VERSION:
             raise ImportError("libseismic_hip.so ABI version mismatch")
         _lib = L
@@ -140,6 +147,17 @@ class NativeIndex:
     def upload(self, device=0):
         check(lib().sgpu_index_upload(self.h, int(device)))
         return self
+
+    def upload_many(self, devices):
+        """Replicate on several devices (replica 0 from the host, the others GPU to GPU);
+        batch_search then shards a batch over the replicas."""
+        ids = np.ascontiguousarray(devices, np.int32)
+        check(lib().sgpu_index_upload_many(self.h, _p(ids), len(ids)))
+        return self
+
+    @property
+    def replicas(self):
+        return int(lib().sgpu_index_replicas(self.h))
 
     # ---- kNN graph (reference Knn, src/inverted_index.rs:430-594) ----
     def build_knn(self, nknn):
@@ -218,14 +236,14 @@ class NativeIndex:
 class DeviceBatch:
     """A query batch resident in HBM (what bench.py times)."""
 
-    def __init__(self, index, q_off, comps, vals, k_max):
+    def __init__(self, index, q_off, comps, vals, k_max, replica=0):
         self.index = index
         self.q_off, self.comps, self.vals = _csr(q_off, comps, vals)
         self.nq = len(self.q_off) - 1
         self.k_max = int(k_max)
         self.h = C.c_void_p()
-        check(lib().sgpu_batch_create(index.h, _p(self.q_off), _p(self.comps), _p(self.vals), self.nq,
-                                      self.k_max, C.byref(self.h)))
+        check(lib().sgpu_batch_create_on(index.h, int(replica), _p(self.q_off), _p(self.comps), _p(self.vals),
+                                         self.nq, self.k_max, C.byref(self.h)))
 
     def run(self, k, query_cut, heap_factor, first_sorted=False, sync=True, n_knn=0):
         p = params(k, query_cut, heap_factor, first_sorted, n_knn)
@@ -295,3 +313,29 @@ def synth(n_vecs, dim, seed, kind=0, docs=None):
     check(lib().sgpu_synth_generate(C.byref(spec), _p(d_off), _p(d_c), _p(d_v), nd, _p(off), _p(comps),
                                     _p(vals), C.byref(nnz)))
     return off, comps[: nnz.value], vals[: nnz.value]
+
+
+def read_inner_format(path):
+    """documents.bin / queries.bin of the reference (scripts/convert_json_to_inner_format.py:10-27)
+    -> (offsets u64, comps u32, vals f32)."""
+    n, nnz = C.c_uint64(0), C.c_uint64(0)
+    check(lib().sgpu_dataset_read(os.fsencode(path), C.byref(n), C.byref(nnz), None, None, None))
+    off = np.zeros(n.value + 1, np.uint64)
+    comps = np.zeros(max(nnz.value, 1), np.uint32)
+    vals = np.zeros(max(nnz.value, 1), np.float32)
+    check(lib().sgpu_dataset_read(os.fsencode(path), C.byref(n), C.byref(nnz), _p(off), _p(comps), _p(vals)))
+    return off, comps[: nnz.value], vals[: nnz.value]
+
+
+def write_inner_format(path, off, comps, vals):
+    off, comps, vals = _csr(off, comps, vals)
+    check(lib().sgpu_dataset_write(os.fsencode(path), len(off) - 1, _p(off), _p(comps), _p(vals)))
+
+
+def write_results_tsv(path, scores, ids, n):
+    """query_index\tdoc_id\trank\tscore (reference src/bin/perf_inverted_index.rs:223-235)."""
+    scores = np.ascontiguousarray(scores, np.float32)
+    ids = np.ascontiguousarray(ids, np.uint64)
+    n = np.ascontiguousarray(n, np.uint32)
+    nq, k = scores.shape if scores.ndim == 2 else (0, 1)
+    check(lib().sgpu_results_write_tsv(os.fsencode(path), nq, k, _p(scores), _p(ids), _p(n)))

@@ -1,6 +1,8 @@
 // abi.cpp — the extern "C" surface declared in include/seismic_hip.h.
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 
 #include "host_index.hpp"
 
@@ -8,22 +10,28 @@ struct sgpu_batch;
 
 namespace sgpu {
 // device_index.hip
+struct Lane;
 sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** out);
+sgpu_status device_index_clone(const DeviceIndex* src, int device, DeviceIndex** out);
 void device_index_free(DeviceIndex* d);
 uint64_t device_index_bytes(const DeviceIndex* d);
-sgpu_status batch_create(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
+Lane* lane_acquire(DeviceIndex* d);
+void lane_release(DeviceIndex* d, Lane* l);
+Lane* lane_main(DeviceIndex* d);
+sgpu_batch** lane_scratch(Lane* l);
+sgpu_status batch_create(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
                          const float* vals, uint32_t nq, uint32_t k_max, sgpu_batch** out);
 void batch_free(sgpu_batch* b);
-sgpu_status batch_run(DeviceIndex* d, sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode, int sync,
-                      sgpu_launch_stats* stats);
+sgpu_status batch_run(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode,
+                      int sync, sgpu_launch_stats* stats);
 sgpu_status batch_sync(DeviceIndex* d, sgpu_launch_stats* stats);
-sgpu_status batch_fetch(DeviceIndex* d, sgpu_batch* b, uint32_t k, float* out_scores, uint64_t* out_ids,
+sgpu_status batch_fetch(DeviceIndex* d, Lane* lane, sgpu_batch* b, uint32_t k, float* out_scores, uint64_t* out_ids,
                         uint32_t* out_n);
 sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out);
 sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list, const uint32_t* comps,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
 int device_count();
-sgpu_batch** device_index_scratch_batch(DeviceIndex* d);
+const DeviceIndex* batch_replica(const sgpu_batch* b);
 sgpu_status device_index_set_knn(DeviceIndex* d, const std::vector<uint32_t>& knn, uint32_t knn_dim);
 sgpu_status build_knn_on_device(DeviceIndex* d, HostIndex& h, uint32_t nknn);
 }  // namespace sgpu
@@ -33,7 +41,7 @@ using namespace sgpu;
 extern "C" {
 
 const char* sgpu_last_error(void) { return last_error().c_str(); }
-uint32_t sgpu_abi_version(void) { return 1; }
+uint32_t sgpu_abi_version(void) { return 2; }
 
 sgpu_status sgpu_device_count(int32_t* n) {
   if (!n) return fail(SGPU_EINVAL, "null argument");
@@ -97,14 +105,39 @@ sgpu_status sgpu_index_load(const char* path, sgpu_index** out) {
   return SGPU_OK;
 }
 
-sgpu_status sgpu_index_upload(sgpu_index* idx, int32_t device) {
-  if (!idx) return fail(SGPU_EINVAL, "null argument");
-  if (idx->dev) {
-    device_index_free(idx->dev);
-    idx->dev = nullptr;
-  }
-  return device_index_upload(idx->host, device, &idx->dev);
+static void drop_replicas(sgpu_index* idx) {
+  for (DeviceIndex* d : idx->replicas) device_index_free(d);
+  idx->replicas.clear();
+  idx->dev = nullptr;
 }
+
+sgpu_status sgpu_index_upload_many(sgpu_index* idx, const int32_t* device_ids, uint32_t n) {
+  if (!idx || !device_ids || n == 0) return fail(SGPU_EINVAL, "null argument / no device given");
+  drop_replicas(idx);
+  // replica 0 is packed on the host and copied over PCIe once; the others are copied from it
+  // GPU to GPU (hipMemcpyPeer: xGMI on an MI355X node) instead of n more host uploads
+  DeviceIndex* first = nullptr;
+  sgpu_status st = device_index_upload(idx->host, device_ids[0], &first);
+  if (st != SGPU_OK) return st;
+  idx->replicas.push_back(first);
+  idx->dev = first;
+  for (uint32_t i = 1; i < n; ++i) {
+    DeviceIndex* r = nullptr;
+    st = device_index_clone(first, device_ids[i], &r);
+    if (st != SGPU_OK) {
+      const std::string msg = last_error();   // the error of the failing replica survives the clean-up
+      drop_replicas(idx);
+      last_error() = msg;
+      return st;
+    }
+    idx->replicas.push_back(r);
+  }
+  return SGPU_OK;
+}
+
+sgpu_status sgpu_index_upload(sgpu_index* idx, int32_t device) { return sgpu_index_upload_many(idx, &device, 1); }
+
+uint32_t sgpu_index_replicas(const sgpu_index* idx) { return idx ? (uint32_t)idx->replicas.size() : 0; }
 
 sgpu_status sgpu_index_set_knn(sgpu_index* idx, const uint32_t* neighbours, uint64_t n_total, uint32_t knn_dim) {
   if (!idx || (n_total && !neighbours)) return fail(SGPU_EINVAL, "null argument");
@@ -116,7 +149,11 @@ sgpu_status sgpu_index_set_knn(sgpu_index* idx, const uint32_t* neighbours, uint
     return fail(SGPU_ENOMEM, "out of memory");
   }
   idx->host.knn_dim = n_total ? knn_dim : 0;
-  return device_index_set_knn(idx->dev, idx->host.knn, idx->host.knn_dim);
+  for (DeviceIndex* d : idx->replicas) {
+    sgpu_status st = device_index_set_knn(d, idx->host.knn, idx->host.knn_dim);
+    if (st != SGPU_OK) return st;
+  }
+  return SGPU_OK;
 }
 
 sgpu_status sgpu_index_get_knn(const sgpu_index* idx, const uint32_t** neighbours, uint64_t* n_total,
@@ -130,71 +167,141 @@ sgpu_status sgpu_index_get_knn(const sgpu_index* idx, const uint32_t** neighbour
 
 sgpu_status sgpu_index_build_knn(sgpu_index* idx, uint32_t nknn) {
   if (!idx) return fail(SGPU_EINVAL, "null argument");
-  return build_knn_on_device(idx->dev, idx->host, nknn);
+  sgpu_status st = build_knn_on_device(idx->dev, idx->host, nknn);   // searches run on replica 0
+  for (size_t i = 1; st == SGPU_OK && i < idx->replicas.size(); ++i)
+    st = device_index_set_knn(idx->replicas[i], idx->host.knn, idx->host.knn_dim);
+  return st;
 }
 
 uint64_t sgpu_index_device_bytes(const sgpu_index* idx) { return idx ? device_index_bytes(idx->dev) : 0; }
 
 void sgpu_index_destroy(sgpu_index* idx) {
   if (!idx) return;
-  if (idx->dev) device_index_free(idx->dev);
+  drop_replicas(idx);
   delete idx;
+}
+
+static DeviceIndex* replica_of(sgpu_index* idx, uint32_t replica) {
+  if (!idx || replica >= idx->replicas.size()) {
+    fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload) / replica out of range");
+    return nullptr;
+  }
+  return idx->replicas[replica];
+}
+static DeviceIndex* replica_of_batch(sgpu_index* idx, const sgpu_batch* b) {
+  for (DeviceIndex* d : idx->replicas)
+    if (batch_replica(b) == d) return d;
+  fail(SGPU_EINVAL, "batch does not belong to this index");
+  return nullptr;
+}
+
+sgpu_status sgpu_batch_create_on(sgpu_index* idx, uint32_t replica, const uint64_t* q_off, const uint32_t* comps,
+                                 const float* vals, uint32_t nq, uint32_t k_max, sgpu_batch** out) {
+  if (!idx || !q_off || !out || (q_off[nq] && (!comps || !vals))) return fail(SGPU_EINVAL, "null argument");
+  *out = nullptr;
+  DeviceIndex* d = replica_of(idx, replica);
+  if (!d) return SGPU_EDEVICE;
+  return batch_create(d, lane_main(d), idx->host.dim, q_off, comps, vals, nq, k_max, out);
 }
 
 sgpu_status sgpu_batch_create(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals,
                               uint32_t nq, uint32_t k_max, sgpu_batch** out) {
-  if (!idx || !q_off || !out || (q_off[nq] && (!comps || !vals))) return fail(SGPU_EINVAL, "null argument");
-  *out = nullptr;
-  return batch_create(idx->dev, idx->host.dim, q_off, comps, vals, nq, k_max, out);
+  return sgpu_batch_create_on(idx, 0, q_off, comps, vals, nq, k_max, out);
 }
 
 sgpu_status sgpu_batch_run(sgpu_index* idx, sgpu_batch* batch, const sgpu_search_params* params, int32_t sync,
                            sgpu_launch_stats* stats) {
   if (!idx || !batch || !params) return fail(SGPU_EINVAL, "null argument");
-  return batch_run(idx->dev, batch, *params, 0 /*MODE_SEARCH*/, sync, stats);
+  DeviceIndex* d = replica_of_batch(idx, batch);
+  if (!d) return SGPU_EINVAL;
+  return batch_run(d, nullptr, batch, *params, 0 /*MODE_SEARCH*/, sync, stats);
 }
 
 sgpu_status sgpu_batch_run_counted(sgpu_index* idx, sgpu_batch* batch, const sgpu_search_params* params,
                                    sgpu_launch_stats* stats) {
   if (!idx || !batch || !params) return fail(SGPU_EINVAL, "null argument");
-  return batch_run(idx->dev, batch, *params, 2 /*MODE_COUNTED*/, 1, stats);
+  DeviceIndex* d = replica_of_batch(idx, batch);
+  if (!d) return SGPU_EINVAL;
+  return batch_run(d, nullptr, batch, *params, 2 /*MODE_COUNTED*/, 1, stats);
 }
 
 sgpu_status sgpu_batch_sync(sgpu_index* idx, sgpu_launch_stats* stats) {
   if (!idx) return fail(SGPU_EINVAL, "null argument");
+  // every replica's main lane; the statistics are replica 0's
+  for (size_t i = idx->replicas.size(); i-- > 1;) {
+    sgpu_status st = batch_sync(idx->replicas[i], nullptr);
+    if (st != SGPU_OK) return st;
+  }
   return batch_sync(idx->dev, stats);
 }
 
 sgpu_status sgpu_batch_fetch(sgpu_index* idx, sgpu_batch* batch, uint32_t k, float* out_scores,
                              uint64_t* out_doc_ids, uint32_t* out_n) {
   if (!idx || !batch || !out_scores || !out_doc_ids || !out_n) return fail(SGPU_EINVAL, "null argument");
-  return batch_fetch(idx->dev, batch, k, out_scores, out_doc_ids, out_n);
+  DeviceIndex* d = replica_of_batch(idx, batch);
+  if (!d) return SGPU_EINVAL;
+  return batch_fetch(d, nullptr, batch, k, out_scores, out_doc_ids, out_n);
 }
 
 sgpu_status sgpu_batch_fetch_stats(sgpu_index* idx, sgpu_batch* batch, uint32_t* out_counters) {
   if (!idx || !batch || !out_counters) return fail(SGPU_EINVAL, "null argument");
-  return batch_fetch_stats(idx->dev, batch, out_counters);
+  DeviceIndex* d = replica_of_batch(idx, batch);
+  if (!d) return SGPU_EINVAL;
+  return batch_fetch_stats(d, batch, out_counters);
 }
 
 void sgpu_batch_destroy(sgpu_batch* batch) { batch_free(batch); }
+
+// One shard of a batch on one replica: borrow a lane (its stream and recycled device batch), H2D of
+// the queries, one kernel pass, D2H of the results. No allocation once the lane's batch has grown to
+// the call's size; calls from different host threads take different lanes and overlap.
+static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
+                                const float* vals, uint32_t nq, const sgpu_search_params& params,
+                                float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n) {
+  Lane* lane = lane_acquire(d);
+  sgpu_batch** slot = lane_scratch(lane);
+  sgpu_status st = batch_create(d, lane, dim, q_off, comps, vals, nq, params.k, slot);
+  if (st == SGPU_OK) st = batch_run(d, lane, *slot, params, 0, 0, nullptr);
+  if (st == SGPU_OK) st = batch_fetch(d, lane, *slot, params.k, out_scores, out_doc_ids, out_n);
+  lane_release(d, lane);
+  return st;
+}
 
 sgpu_status sgpu_batch_search(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals,
                               uint32_t nq, const sgpu_search_params* params, float* out_scores,
                               uint64_t* out_doc_ids, uint32_t* out_n) {
   if (!idx || !params || !q_off || !out_scores || !out_doc_ids || !out_n) return fail(SGPU_EINVAL, "null argument");
   if (params->k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
-  if (!idx->dev) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
+  if (idx->replicas.empty()) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
   if (q_off[nq] && (!comps || !vals)) return fail(SGPU_EINVAL, "null argument");
-  // one recycled device batch per index: a call costs the H2D of the queries, one kernel pass and
-  // the D2H of the results, no allocation (calls on one index are serialised by this mutex)
-  static std::mutex scratch_mu;
-  std::lock_guard<std::mutex> lock(scratch_mu);
-  sgpu_batch** slot = device_index_scratch_batch(idx->dev);
-  sgpu_status st = batch_create(idx->dev, idx->host.dim, q_off, comps, vals, nq, params->k, slot);
-  if (st != SGPU_OK) return st;
-  st = batch_run(idx->dev, *slot, *params, 0, 1, nullptr);
-  if (st == SGPU_OK) st = batch_fetch(idx->dev, *slot, params->k, out_scores, out_doc_ids, out_n);
-  return st;
+  const uint32_t n_rep = (uint32_t)idx->replicas.size();
+  if (n_rep == 1 || nq < 2 * n_rep)
+    return search_shard(idx->dev, idx->host.dim, q_off, comps, vals, nq, *params, out_scores, out_doc_ids, out_n);
+  // Index replicated on several GPUs: contiguous shards of the batch, one host thread per GPU, no
+  // collective; results land in input order (the reference's rayon loop over queries,
+  // src/pylib/mod.rs:629-652, 1129-1145, becomes one shard per device).
+  std::vector<sgpu_status> sts(n_rep, SGPU_OK);
+  std::vector<std::string> msgs(n_rep);
+  std::vector<std::thread> threads;
+  const uint32_t k = params->k;
+  for (uint32_t r = 0; r < n_rep; ++r) {
+    const uint32_t q0 = (uint32_t)((uint64_t)nq * r / n_rep), q1 = (uint32_t)((uint64_t)nq * (r + 1) / n_rep);
+    threads.emplace_back([=, &sts, &msgs]() {
+      std::vector<uint64_t> off(q1 - q0 + 1);
+      for (uint32_t q = q0; q <= q1; ++q) off[q - q0] = q_off[q] - q_off[q0];
+      sts[r] = search_shard(idx->replicas[r], idx->host.dim, off.data(), comps ? comps + q_off[q0] : nullptr,
+                            vals ? vals + q_off[q0] : nullptr, q1 - q0, *params, out_scores + (size_t)q0 * k,
+                            out_doc_ids + (size_t)q0 * k, out_n + q0);
+      if (sts[r] != SGPU_OK) msgs[r] = last_error();
+    });
+  }
+  for (auto& t : threads) t.join();
+  for (uint32_t r = 0; r < n_rep; ++r)
+    if (sts[r] != SGPU_OK) {
+      last_error() = msgs[r];
+      return sts[r];
+    }
+  return SGPU_OK;
 }
 
 sgpu_status sgpu_search(sgpu_index* idx, const uint32_t* comps, const float* vals, uint32_t nnz,

@@ -3,10 +3,13 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
+
+#include <omp.h>
 
 #include "device_types.hpp"
 #include "host_index.hpp"
@@ -27,40 +30,103 @@ struct sgpu_batch;
 namespace sgpu {
 void batch_free(sgpu_batch* b);
 
+// One stream's worth of launch state. The device-resident batch API (sgpu_batch_*) runs on the
+// index's `main` lane; sgpu_search / sgpu_batch_search borrow a lane from a small pool, so calls
+// from several host threads on one index overlap (copies and kernels of different lanes run
+// concurrently on the device) - the reference's `search(&self)` is re-entrant, S: Sync
+// (src/index_traits.rs:106-113).
+struct Lane {
+  hipStream_t stream = nullptr;
+  uint32_t* queue = nullptr;       // the launch's work counter (queries are pulled from it)
+  sgpu_batch* scratch = nullptr;   // pool lanes: the recycled device batch (no allocation per call)
+  std::vector<hipEvent_t> ev0, ev1;   // timing of enqueued launches
+  int ev_pending = 0;
+  double sum_ms = 0;
+  uint32_t n_timed = 0;
+  sgpu_launch_stats last{};
+  bool busy = false;
+};
+
+struct Alloc {
+  void* p;
+  size_t bytes;
+  size_t field;   // byte offset (inside DeviceIndex) of the view pointer that refers to it
+};
+
 struct DeviceIndex {
   int device = -1;
-  hipStream_t stream = nullptr;
   DevView view{};
   uint32_t comp_width = 2;
-  std::vector<void*> allocs;
+  std::vector<Alloc> allocs;
   uint64_t bytes = 0;
   uint32_t n_cu = 0;
   uint32_t max_lds = 0;
   std::vector<uint32_t> list_nb, list_np;   // blocks / postings per posting list (host copy)
   uint32_t max_nb = 0;
-  // per-launch scratch
-  sgpu_batch* scratch = nullptr;   // recycled by sgpu_search / sgpu_batch_search
+  static constexpr int kMainEvents = 64, kPool = 4;
+  Lane main;
+  Lane pool[kPool];
   std::unordered_map<uint64_t, int> occupancy;   // kernel variant + LDS size -> workgroups per CU
-  uint32_t* queue = nullptr;
-  uint32_t* bitmaps = nullptr;
+  uint32_t* bitmaps = nullptr;                   // visited bitmaps of the counted pass (main lane only)
   uint32_t bitmaps_slots = 0;
-  // timing of enqueued launches
-  static constexpr int kEvents = 64;
-  hipEvent_t ev0[kEvents], ev1[kEvents];
-  int ev_pending = 0;
-  bool ev_ready = false;
-  double sum_ms = 0;
-  uint32_t n_timed = 0;
-  sgpu_launch_stats last{};
-  std::mutex mu;
+  std::mutex mu;        // main lane, occupancy cache, bitmaps
+  std::mutex pool_mu;   // pool lane hand-out
+  std::condition_variable pool_cv;
 };
+
+static sgpu_status lane_init(Lane* l, int n_events) {
+  if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess)
+    return fail(SGPU_EDEVICE, "hipStreamCreate failed");
+  if (hipMalloc((void**)&l->queue, 256) != hipSuccess) return fail(SGPU_ENOMEM, "hipMalloc(queue) failed");
+  for (int i = 0; i < n_events; ++i) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return fail(SGPU_EDEVICE, "hipEventCreate failed");
+    l->ev0.push_back(a);
+    if (hipEventCreate(&b) != hipSuccess) return fail(SGPU_EDEVICE, "hipEventCreate failed");
+    l->ev1.push_back(b);
+  }
+  return SGPU_OK;
+}
+
+static void lane_free(Lane* l) {
+  if (l->stream) (void)hipStreamSynchronize(l->stream);
+  if (l->scratch) batch_free(l->scratch);
+  if (l->queue) (void)hipFree(l->queue);
+  for (hipEvent_t e : l->ev0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : l->ev1) (void)hipEventDestroy(e);
+  if (l->stream) (void)hipStreamDestroy(l->stream);
+  *l = Lane{};
+}
+
+Lane* lane_acquire(DeviceIndex* d) {
+  std::unique_lock<std::mutex> lk(d->pool_mu);
+  for (;;) {
+    for (Lane& l : d->pool)
+      if (!l.busy) {
+        l.busy = true;
+        return &l;
+      }
+    d->pool_cv.wait(lk);
+  }
+}
+
+void lane_release(DeviceIndex* d, Lane* l) {
+  {
+    std::lock_guard<std::mutex> lk(d->pool_mu);
+    l->busy = false;
+  }
+  d->pool_cv.notify_one();
+}
+
+Lane* lane_main(DeviceIndex* d) { return &d->main; }
+sgpu_batch** lane_scratch(Lane* l) { return &l->scratch; }
 
 template <class T>
 static sgpu_status dev_copy(DeviceIndex* d, const T* src, size_t n, const T** out) {
   void* p = nullptr;
   const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
   if (hipMalloc(&p, bytes) != hipSuccess) return fail(SGPU_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
-  d->allocs.push_back(p);
+  d->allocs.push_back(Alloc{p, bytes, (size_t)((const char*)out - (const char*)d)});
   d->bytes += bytes;
   if (n) HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
   *out = (const T*)p;
@@ -70,17 +136,10 @@ static sgpu_status dev_copy(DeviceIndex* d, const T* src, size_t n, const T** ou
 void device_index_free(DeviceIndex* d) {
   if (!d) return;
   if (d->device >= 0) (void)hipSetDevice(d->device);
-  if (d->stream) (void)hipStreamSynchronize(d->stream);
-  if (d->scratch) batch_free(d->scratch);
-  for (void* p : d->allocs) (void)hipFree(p);
-  if (d->queue) (void)hipFree(d->queue);
+  lane_free(&d->main);
+  for (Lane& l : d->pool) lane_free(&l);
+  for (const Alloc& a : d->allocs) (void)hipFree(a.p);
   if (d->bitmaps) (void)hipFree(d->bitmaps);
-  if (d->ev_ready)
-    for (int i = 0; i < DeviceIndex::kEvents; ++i) {
-      (void)hipEventDestroy(d->ev0[i]);
-      (void)hipEventDestroy(d->ev1[i]);
-    }
-  if (d->stream) (void)hipStreamDestroy(d->stream);
   delete d;
 }
 
@@ -113,13 +172,9 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(fail(SGPU_EDEVICE, "hipGetDeviceProperties failed"));
   d->n_cu = (uint32_t)prop.multiProcessorCount;
   d->max_lds = (uint32_t)prop.sharedMemPerBlock;
-  if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess)
-    return bail(fail(SGPU_EDEVICE, "hipStreamCreate failed"));
-  for (int i = 0; i < DeviceIndex::kEvents; ++i) {
-    if (hipEventCreate(&d->ev0[i]) != hipSuccess || hipEventCreate(&d->ev1[i]) != hipSuccess)
-      return bail(fail(SGPU_EDEVICE, "hipEventCreate failed"));
-  }
-  d->ev_ready = true;
+  if ((st = lane_init(&d->main, DeviceIndex::kMainEvents)) != SGPU_OK) return bail(st);
+  for (Lane& l : d->pool)
+    if ((st = lane_init(&l, 1)) != SGPU_OK) return bail(st);
 
   try {
     const uint32_t cw = h.comp_width;
@@ -198,9 +253,9 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       if ((st = dev_copy(d, h.row_ptr.data(), h.row_ptr.size(), &d->view.row_ptr)) != SGPU_OK) return bail(st);
     }
     {
-      const uint8_t* rc = nullptr;
-      if ((st = dev_copy(d, h.row_comp.data(), h.row_comp.size(), &rc)) != SGPU_OK) return bail(st);
-      d->view.row_comp = rc;
+      static_assert(sizeof(d->view.row_comp) == sizeof(const uint8_t*), "pointer field");
+      if ((st = dev_copy(d, h.row_comp.data(), h.row_comp.size(), (const uint8_t**)&d->view.row_comp)) != SGPU_OK)
+        return bail(st);
     }
     if ((st = dev_copy(d, h.sum_bid.data(), h.sum_bid.size(), &d->view.sum_bid)) != SGPU_OK) return bail(st);
     {
@@ -252,10 +307,62 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       d->list_np[c] = (uint32_t)(h.block_post_start[h.list_block_start[c + 1]] - h.block_post_start[h.list_block_start[c]]);
       d->max_nb = std::max(d->max_nb, d->list_nb[c]);
     }
-    if (hipMalloc((void**)&d->queue, 256) != hipSuccess) return bail(fail(SGPU_ENOMEM, "hipMalloc(queue) failed"));
   } catch (const std::bad_alloc&) {
     return bail(fail(SGPU_ENOMEM, "out of host memory packing the index for upload"));
   }
+  *out = d;
+  return SGPU_OK;
+}
+
+// A replica of `src` on HIP device `device`: every array is copied GPU to GPU (hipMemcpyPeer goes
+// over xGMI between the MI355Xs of a node; same-device "replicas" are plain device copies), nothing
+// is repacked or re-sent from the host.
+sgpu_status device_index_clone(const DeviceIndex* src, int device, DeviceIndex** out) {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(SGPU_EDEVICE, "no HIP device available");
+  if (device < 0 || device >= n_dev) return fail(SGPU_EDEVICE, "device %d out of range (0..%d)", device, n_dev - 1);
+  HIP_TRY(hipSetDevice(device));
+  if (device != src->device) {
+    int can = 0;
+    (void)hipDeviceCanAccessPeer(&can, device, src->device);
+    if (can) {
+      const hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+    }
+  }
+  DeviceIndex* d = new DeviceIndex();
+  d->device = device;
+  d->comp_width = src->comp_width;
+  d->view = src->view;
+  d->n_cu = src->n_cu;
+  d->max_lds = src->max_lds;
+  d->list_nb = src->list_nb;
+  d->list_np = src->list_np;
+  d->max_nb = src->max_nb;
+  auto bail = [&](sgpu_status s) {
+    device_index_free(d);
+    return s;
+  };
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return bail(fail(SGPU_EDEVICE, "hipGetDeviceProperties failed"));
+  d->n_cu = (uint32_t)prop.multiProcessorCount;
+  d->max_lds = (uint32_t)prop.sharedMemPerBlock;
+  sgpu_status st;
+  if ((st = lane_init(&d->main, DeviceIndex::kMainEvents)) != SGPU_OK) return bail(st);
+  for (Lane& l : d->pool)
+    if ((st = lane_init(&l, 1)) != SGPU_OK) return bail(st);
+  // pointers of the copied view must not be freed if an allocation below fails half way
+  for (const Alloc& a : src->allocs) *(const void**)((char*)d + a.field) = nullptr;
+  for (const Alloc& a : src->allocs) {
+    void* p = nullptr;
+    if (hipMalloc(&p, a.bytes) != hipSuccess) return bail(fail(SGPU_ENOMEM, "hipMalloc of %zu bytes failed on device %d", a.bytes, device));
+    d->allocs.push_back(Alloc{p, a.bytes, a.field});
+    d->bytes += a.bytes;
+    *(const void**)((char*)d + a.field) = p;
+    const hipError_t e = hipMemcpyPeerAsync(p, device, a.p, src->device, a.bytes, d->main.stream);
+    if (e != hipSuccess) return bail(fail(SGPU_EDEVICE, "hipMemcpyPeerAsync %d -> %d failed: %s", src->device, device, hipGetErrorString(e)));
+  }
+  if (hipStreamSynchronize(d->main.stream) != hipSuccess) return bail(fail(SGPU_EDEVICE, "peer copy failed"));
   *out = d;
   return SGPU_OK;
 }
@@ -265,11 +372,11 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
 // ---------------------------------------------------------------------------
 }  // namespace sgpu
 
-struct sgpu_batch_plan {   // per (batch, query_cut): LDS need and processing order
+struct sgpu_batch_plan {   // per (batch, query_cut): LDS need and processing order (host side)
   uint32_t query_cut = 0;
   uint32_t dots_cap = 1;    // max over queries of the blocks of the lists it walks
   uint32_t max_nb = 0;      // largest single list walked first (sort buffer sizing)
-  uint32_t* d_order = nullptr;
+  std::vector<uint32_t> order;   // queries, longest expected first
 };
 
 struct sgpu_batch {
@@ -278,15 +385,19 @@ struct sgpu_batch {
   std::vector<float> h_val;
   std::vector<sgpu_batch_plan> plans;
   int device = -1;
+  const sgpu::DeviceIndex* owner = nullptr;   // the replica the batch was created on
   uint32_t nq = 0, k_max = 0, max_nnz = 0;
   uint64_t cap_nq = 0, cap_nnz = 0, cap_slab = 0;   // allocated capacities (a scratch batch is reused)
   uint32_t* q_off = nullptr;
   uint32_t* q_comp = nullptr;
   float* q_val = nullptr;
+  uint32_t* q_order = nullptr;     // cap_nq: the processing order of the plan named by order_cut
+  uint32_t* h_order = nullptr;     // its pinned host staging copy (the H2D is then truly asynchronous)
+  uint32_t order_cut = 0xffffffffu;
   float* out_scores = nullptr;
   uint64_t* out_ids = nullptr;
   uint32_t* out_n = nullptr;
-  uint32_t* out_stats = nullptr;   // nq x 8 work counters of the last pass
+  uint32_t* out_stats = nullptr;   // nq x STATS_WORDS work counters of the last pass
 };
 
 namespace sgpu {
@@ -306,16 +417,32 @@ sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t
     const uint64_t n = q_off[q + 1] - q_off[q];
     if (n > 0xffffu) return fail(SGPU_ELIMIT, "query %u has %llu components (limit 65535)", q, (unsigned long long)n);
     mx = std::max<uint32_t>(mx, (uint32_t)n);
-    for (uint64_t i = q_off[q]; i < q_off[q + 1]; ++i) {
-      // InvertedIndexBase::search asserts sorted components (reference src/inverted_index.rs:172-175)
-      // and indexes posting_lists[component] (bounds panic, :193); duplicates are rejected too.
-      if (comps[i] >= dim) return fail(SGPU_EINVAL, "query %u: component %u >= dim", q, comps[i]);
-      if (i > q_off[q] && comps[i] <= comps[i - 1])
-        return fail(SGPU_EINVAL, "query %u: components must be strictly ascending", q);
-      if (std::isnan(vals[i])) return fail(SGPU_EINVAL, "query %u: NaN value", q);
-    }
   }
   if (q_off[nq] >= 0xffffffffull) return fail(SGPU_ELIMIT, "batch too large");
+  if (q_off[nq] && (!comps || !vals)) return fail(SGPU_EINVAL, "null query arrays");
+  // InvertedIndexBase::search asserts sorted components (reference src/inverted_index.rs:172-175)
+  // and indexes posting_lists[component] (bounds panic, :193); duplicates are rejected too.
+  int bad_kind = 0;
+  uint32_t bad_q = 0xffffffffu;
+#pragma omp parallel for schedule(static) if (nq >= 2048)
+  for (int64_t q = 0; q < (int64_t)nq; ++q) {
+    int kind = 0;
+    for (uint64_t i = q_off[q]; i < q_off[q + 1] && !kind; ++i) {
+      if (comps[i] >= dim) kind = 1;
+      else if (i > q_off[q] && comps[i] <= comps[i - 1]) kind = 2;
+      else if (std::isnan(vals[i])) kind = 3;
+    }
+    if (kind) {
+#pragma omp critical
+      if ((uint32_t)q < bad_q) {
+        bad_q = (uint32_t)q;
+        bad_kind = kind;
+      }
+    }
+  }
+  if (bad_kind == 1) return fail(SGPU_EINVAL, "query %u: component >= dim", bad_q);
+  if (bad_kind == 2) return fail(SGPU_EINVAL, "query %u: components must be strictly ascending", bad_q);
+  if (bad_kind == 3) return fail(SGPU_EINVAL, "query %u: NaN value", bad_q);
   *max_nnz = mx;
   return SGPU_OK;
 }
@@ -326,68 +453,82 @@ void batch_free(sgpu_batch* b) {
   (void)hipFree(b->q_off);
   (void)hipFree(b->q_comp);
   (void)hipFree(b->q_val);
+  (void)hipFree(b->q_order);
+  (void)hipHostFree(b->h_order);
   (void)hipFree(b->out_scores);
   (void)hipFree(b->out_ids);
   (void)hipFree(b->out_n);
   (void)hipFree(b->out_stats);
-  for (auto& pl : b->plans) (void)hipFree(pl.d_order);
   delete b;
 }
 
-sgpu_status batch_create(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
+// Creates (or, when *out already holds a large enough batch of the same device, refills) a device
+// batch. The copies are enqueued on `lane`'s stream; the host arrays are pageable, so they are
+// staged before the calls return and the caller's buffers are not referenced afterwards.
+sgpu_status batch_create(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
                          const float* vals, uint32_t nq, uint32_t k_max, sgpu_batch** out) {
   if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
   if (k_max == 0) return fail(SGPU_EINVAL, "k == 0");
-  if (k_max > 1024) return fail(SGPU_ELIMIT, "k = %u exceeds the register heap limit of 1024", k_max);
+  if (k_max > 1024) return fail(SGPU_ELIMIT, "k = %u exceeds the heap limit of 1024", k_max);
   uint32_t max_nnz = 0;
   sgpu_status st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz);
   if (st != SGPU_OK) return st;
   HIP_TRY(hipSetDevice(d->device));
   const uint64_t nnz = q_off[nq];
   const size_t slab = std::max<size_t>((size_t)nq * k_max, 1);
-  // *out may hold a batch to recycle (sgpu_search / sgpu_batch_search keep one per index so that a
-  // call does not pay seven hipMalloc/hipFree round trips)
   sgpu_batch* b = *out;
-  const bool reuse = b && b->device == d->device && b->cap_nq >= nq && b->cap_nnz >= nnz && b->cap_slab >= slab;
+  const bool reuse = b && b->owner == d && b->cap_nq >= nq && b->cap_nnz >= nnz && b->cap_slab >= slab;
   if (b && !reuse) {
+    HIP_TRY(hipStreamSynchronize(lane->stream));
     batch_free(b);
     b = nullptr;
     *out = nullptr;
   }
-  if (!b) b = new sgpu_batch();
-  b->device = d->device;
-  b->nq = nq;
-  b->k_max = k_max;
-  b->max_nnz = max_nnz;
-  for (auto& pl : b->plans) (void)hipFree(pl.d_order);
-  b->plans.clear();
-  b->h_off.assign(q_off, q_off + nq + 1);
-  b->h_comp.assign(comps, comps + nnz);
-  b->h_val.assign(vals, vals + nnz);
+  try {
+    if (!b) b = new sgpu_batch();
+    b->device = d->device;
+    b->owner = d;
+    b->nq = nq;
+    b->k_max = k_max;
+    b->max_nnz = max_nnz;
+    b->plans.clear();
+    b->order_cut = 0xffffffffu;
+    b->h_off.assign(q_off, q_off + nq + 1);
+    b->h_comp.assign(comps, comps + nnz);
+    b->h_val.assign(vals, vals + nnz);
+  } catch (const std::bad_alloc&) {
+    if (!reuse) delete b;
+    return fail(SGPU_ENOMEM, "out of host memory creating a query batch");
+  }
   std::vector<uint32_t> off32(nq + 1);
   for (uint32_t q = 0; q <= nq; ++q) off32[q] = (uint32_t)q_off[q];
   bool ok = true;
   if (!reuse) {
-    b->cap_nq = nq;
-    b->cap_nnz = nnz;
+    // a recycled batch grows geometrically so that a stream of slightly different calls settles
+    b->cap_nq = std::max<uint64_t>(nq, 1);
+    b->cap_nnz = std::max<uint64_t>(nnz, 1);
     b->cap_slab = slab;
-    ok = hipMalloc((void**)&b->q_off, (nq + 1) * 4) == hipSuccess &&
-            hipMalloc((void**)&b->q_comp, std::max<uint64_t>(nnz, 1) * 4) == hipSuccess &&
-            hipMalloc((void**)&b->q_val, std::max<uint64_t>(nnz, 1) * 4) == hipSuccess &&
-            hipMalloc((void**)&b->out_scores, std::max<size_t>(slab, 65536) * 4) == hipSuccess &&
-            hipMalloc((void**)&b->out_ids, slab * 8) == hipSuccess &&
-            hipMalloc((void**)&b->out_n, std::max<uint32_t>(nq, 1) * 4) == hipSuccess &&
-            hipMalloc((void**)&b->out_stats, std::max<uint32_t>(nq, 1) * STATS_WORDS * 4) == hipSuccess;
+    ok = hipMalloc((void**)&b->q_off, (b->cap_nq + 1) * 4) == hipSuccess &&
+         hipMalloc((void**)&b->q_comp, b->cap_nnz * 4) == hipSuccess &&
+         hipMalloc((void**)&b->q_val, b->cap_nnz * 4) == hipSuccess &&
+         hipMalloc((void**)&b->q_order, b->cap_nq * 4) == hipSuccess &&
+         hipHostMalloc((void**)&b->h_order, b->cap_nq * 4, hipHostMallocDefault) == hipSuccess &&
+         hipMalloc((void**)&b->out_scores, std::max<size_t>(slab, 65536) * 4) == hipSuccess &&
+         hipMalloc((void**)&b->out_ids, slab * 8) == hipSuccess &&
+         hipMalloc((void**)&b->out_n, b->cap_nq * 4) == hipSuccess &&
+         hipMalloc((void**)&b->out_stats, b->cap_nq * STATS_WORDS * 4) == hipSuccess;
   }
   if (!ok) {
     batch_free(b);
     *out = nullptr;
     return fail(SGPU_ENOMEM, "hipMalloc failed creating a query batch");
   }
-  ok = hipMemcpy(b->q_off, off32.data(), (nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
-       (nnz == 0 || (hipMemcpy(b->q_comp, comps, nnz * 4, hipMemcpyHostToDevice) == hipSuccess &&
-                     hipMemcpy(b->q_val, vals, nnz * 4, hipMemcpyHostToDevice) == hipSuccess));
+  ok = hipMemcpyAsync(b->q_off, off32.data(), (nq + 1) * 4, hipMemcpyHostToDevice, lane->stream) == hipSuccess &&
+       (nnz == 0 ||
+        (hipMemcpyAsync(b->q_comp, comps, nnz * 4, hipMemcpyHostToDevice, lane->stream) == hipSuccess &&
+         hipMemcpyAsync(b->q_val, vals, nnz * 4, hipMemcpyHostToDevice, lane->stream) == hipSuccess));
   if (!ok) {
+    (void)hipStreamSynchronize(lane->stream);
     batch_free(b);
     *out = nullptr;
     return fail(SGPU_EDEVICE, "hipMemcpy of the query batch failed");
@@ -396,10 +537,7 @@ sgpu_status batch_create(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, co
   return SGPU_OK;
 }
 
-// the recycled batch behind sgpu_search / sgpu_batch_search
-sgpu_batch** device_index_scratch_batch(DeviceIndex* d) { return d ? &d->scratch : nullptr; }
-
-static inline uint32_t up16(uint32_t x) { return (x + 15u) & ~15u; }
+const DeviceIndex* batch_replica(const sgpu_batch* b) { return b ? b->owner : nullptr; }
 
 // Which lists each query will walk (the device applies the same rule: query_cut heaviest
 // components by f32::total_cmp, ties by ascending component), hence how many block dots it
@@ -410,43 +548,51 @@ static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, c
       *out = &pl;
       return SGPU_OK;
     }
-  sgpu_batch_plan pl;
-  pl.query_cut = query_cut;
-  std::vector<std::pair<uint64_t, uint32_t>> cost(b->nq);
-  std::vector<std::pair<int32_t, uint32_t>> kv;
-  for (uint32_t q = 0; q < b->nq; ++q) {
-    kv.clear();
-    for (uint64_t i = b->h_off[q]; i < b->h_off[q + 1]; ++i) kv.emplace_back(total_key(b->h_val[i]), b->h_comp[i]);
-    const size_t nl = std::min<size_t>(query_cut, kv.size());
-    std::partial_sort(kv.begin(), kv.begin() + (long)nl, kv.end(),
-                      [](const std::pair<int32_t, uint32_t>& a, const std::pair<int32_t, uint32_t>& c) {
-                        if (a.first != c.first) return a.first > c.first;
-                        return a.second < c.second;
-                      });
-    uint64_t np = 0;
-    uint32_t nb = 0;
-    for (size_t i = 0; i < nl; ++i) {
-      nb += d->list_nb[kv[i].second];
-      np += d->list_np[kv[i].second];
+  try {
+    sgpu_batch_plan pl;
+    pl.query_cut = query_cut;
+    std::vector<std::pair<uint64_t, uint32_t>> cost(b->nq);
+    uint32_t max_nb = 0, dots_cap = 1;
+#pragma omp parallel if (b->nq >= 2048) reduction(max : max_nb, dots_cap)
+    {
+      std::vector<std::pair<int32_t, uint32_t>> kv;
+#pragma omp for schedule(static)
+      for (int64_t q = 0; q < (int64_t)b->nq; ++q) {
+        kv.clear();
+        for (uint64_t i = b->h_off[q]; i < b->h_off[q + 1]; ++i) kv.emplace_back(total_key(b->h_val[i]), b->h_comp[i]);
+        const size_t nl = std::min<size_t>(query_cut, kv.size());
+        std::partial_sort(kv.begin(), kv.begin() + (long)nl, kv.end(),
+                          [](const std::pair<int32_t, uint32_t>& a, const std::pair<int32_t, uint32_t>& c) {
+                            if (a.first != c.first) return a.first > c.first;
+                            return a.second < c.second;
+                          });
+        uint64_t np = 0;
+        uint32_t nb = 0;
+        for (size_t i = 0; i < nl; ++i) {
+          nb += d->list_nb[kv[i].second];
+          np += d->list_np[kv[i].second];
+        }
+        if (nl) max_nb = std::max(max_nb, d->list_nb[kv[0].second]);
+        dots_cap = std::max(dots_cap, nb);
+        cost[(size_t)q] = {np, (uint32_t)q};
+      }
     }
-    if (nl) pl.max_nb = std::max(pl.max_nb, d->list_nb[kv[0].second]);
-    pl.dots_cap = std::max(pl.dots_cap, nb);
-    cost[q] = {np, q};
+    pl.max_nb = max_nb;
+    pl.dots_cap = dots_cap;
+    std::stable_sort(cost.begin(), cost.end(),
+                     [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) { return a.first > c.first; });
+    pl.order.resize(b->nq);
+    for (uint32_t i = 0; i < b->nq; ++i) pl.order[i] = cost[i].second;
+    b->plans.push_back(std::move(pl));
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of host memory planning a query batch");
   }
-  std::stable_sort(cost.begin(), cost.end(),
-                   [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) { return a.first > c.first; });
-  std::vector<uint32_t> order(b->nq);
-  for (uint32_t i = 0; i < b->nq; ++i) order[i] = cost[i].second;
-  if (hipMalloc((void**)&pl.d_order, std::max<uint32_t>(b->nq, 1) * 4) != hipSuccess)
-    return fail(SGPU_ENOMEM, "hipMalloc(q_order) failed");
-  if (b->nq) HIP_TRY(hipMemcpy(pl.d_order, order.data(), (size_t)b->nq * 4, hipMemcpyHostToDevice));
-  b->plans.push_back(pl);
   *out = &b->plans.back();
   return SGPU_OK;
 }
 
-// Chooses block size, LDS layout and grid for one search pass.
-static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode,
+// Chooses block size, LDS layout and grid for one search pass (caller holds d->mu).
+static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode,
                              LaunchArgs* a) {
   if (sp.k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
   if (sp.k > b->k_max) return fail(SGPU_EINVAL, "k = %u exceeds the batch's k_max = %u", sp.k, b->k_max);
@@ -457,51 +603,60 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   if (NT != 512 && NT != 1024) return fail(SGPU_EINVAL, "SGPU_BLOCK must be 512 or 1024");
   const uint32_t qn = std::max<uint32_t>(4, (b->max_nnz + 3u) & ~3u);
   const bool searching = mode != MODE_DOTS;
-  const uint32_t qc = std::max<uint32_t>(1, std::min<uint32_t>(mode == MODE_DOTS ? 1u : sp.query_cut, qn));
+  // lists walked per query. query_cut == 0 walks none: the reference's k_largest_by(0) selects no
+  // list and the result is empty (src/inverted_index.rs:187-190); the LDS tables keep one slot.
+  const uint32_t cut = mode == MODE_DOTS ? 1u : std::min<uint32_t>(sp.query_cut, qn);
+  const uint32_t qc = std::max<uint32_t>(1, cut);
   const uint32_t words = (d->view.dim + 31) / 32;
   uint32_t items_max = env_u32("SGPU_ITEMS_MAX", 1024);
   uint32_t dots_cap = 1, sort_nb = 0;
-  const uint32_t* d_order = nullptr;
+  const sgpu_batch_plan* pl = nullptr;
   if (mode == MODE_DOTS) {
     dots_cap = std::max<uint32_t>(1, d->list_nb[sp.query_cut]);
   } else {
-    const sgpu_batch_plan* pl = nullptr;
-    sgpu_status pst = plan_for(d, b, qc, &pl);
+    sgpu_status pst = plan_for(d, b, cut, &pl);
     if (pst != SGPU_OK) return pst;
     dots_cap = pl->dots_cap;
     sort_nb = pl->max_nb;
-    d_order = env_u32("SGPU_NO_LPT", 0) ? nullptr : pl->d_order;
   }
+  // LDS layout, computed in 64 bits (qc * qn reaches 2^32 for 64K-component queries) and checked
+  // against the limit before it is narrowed
+  const uint64_t lds_limit = std::min<uint32_t>(d->max_lds ? d->max_lds : 65536, 160 * 1024);
+  auto up = [](uint64_t x) { return (x + 15ull) & ~15ull; };
   LdsLayout L{};
-  uint32_t o = 0;
-  L.q_comp = o; o += up16(qn * 4);
-  L.q_val = o; o += up16((qn + 1) * 4);   // + the 0.0 slot non-matching components resolve to
-  L.sel = o; o += up16((6 * qc + 1) * 4);
-  L.rt_start = o; o += up16(qc * qn * 8);
-  L.rt_mid = o; o += up16(qc * qn * 2);
-  L.rt_pre = o; o += up16(2 * qc * (qn + 1) * 4);   // two streams (block-id halves) per list
-  L.dots = o; o += up16(dots_cap * 4);
-  L.order = o; o += up16((sp.first_sorted && searching) ? sort_nb * 2 : 0);
-  L.part = o; o += up16(2 * (NT / 64 + 1) * 4);   // two scan scratch areas, used alternately
-  L.st = o; o += up16(kStateWords * 4);   // state words + candidate lists
+  uint64_t o = 0;
+  L.q_comp = (uint32_t)o; o += up((uint64_t)qn * 4);
+  L.q_val = (uint32_t)o; o += up(((uint64_t)qn + 1) * 4);   // + the 0.0 slot non-matching components resolve to
+  L.sel = (uint32_t)o; o += up((6ull * qc + 1) * 4);
+  if (o + up((uint64_t)qc * qn * 8) > lds_limit)
+    return fail(SGPU_ELIMIT, "query_cut %u x %u query components do not fit the row tables in LDS", qc, qn);
+  L.rt_start = (uint32_t)o; o += up((uint64_t)qc * qn * 8);
+  L.rt_mid = (uint32_t)o; o += up((uint64_t)qc * qn * 2);
+  L.rt_pre = (uint32_t)o; o += up(2ull * qc * (qn + 1) * 4);   // two streams (block-id halves) per list
+  L.dots = (uint32_t)o; o += up((uint64_t)dots_cap * 4);
+  L.order = (uint32_t)o; o += up((sp.first_sorted && searching) ? (uint64_t)sort_nb * 2 : 0);
+  L.part = (uint32_t)o; o += up(2 * (NT / 64 + 1) * 4);   // two scan scratch areas, used alternately
+  L.st = (uint32_t)o; o += up(kStateWords * 4);   // state words + candidate lists
   // [lookup table | union region (sort keys, item tables)]
-  uint32_t sort_bytes = 0;
+  uint64_t sort_bytes = 0;
   if (sp.first_sorted && searching && sort_nb > 1) {
-    uint32_t n2 = 1;
+    uint64_t n2 = 1;
     while (n2 < sort_nb) n2 <<= 1;
     sort_bytes = n2 * 8;
   }
-  const uint32_t lds_limit = std::min<uint32_t>(d->max_lds ? d->max_lds : 65536, 160 * 1024);
-  const uint32_t budget = env_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
+  if (o > lds_limit)
+    return fail(SGPU_ELIMIT, "query needs %llu bytes of LDS before its lookup table (dots %u blocks) > %llu available",
+                (unsigned long long)o, dots_cap, (unsigned long long)lds_limit);
+  const uint64_t budget = env_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
   // query lookup table: dense u8 index (1 B per vocabulary id + the padding sentinel) when it is
   // allowed and fits at 2 workgroups per CU, else {bits, rank} per 32 vocabulary ids
-  const uint32_t dense_bytes = up16(d->view.dim + 1), bitmap_bytes = up16(words * 8);
+  const uint64_t dense_bytes = up((uint64_t)d->view.dim + 1), bitmap_bytes = up((uint64_t)words * 8);
   const bool dense_ok = d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255 &&
                         !env_u32("SGPU_NO_DENSE", 0) && searching;
-  const uint32_t split_bits = up16(words * 4), split_bytes = split_bits + up16(words * 2);
+  const uint64_t split_bits = up((uint64_t)words * 4), split_bytes = split_bits + up((uint64_t)words * 2);
   // the round's item tables shrink (down to 256 items) if that is what keeps 2 workgroups per CU
-  auto uni_for = [&](uint32_t items) { return up16(std::max(items * 16 + NT * 12, sort_bytes)); };
-  const uint32_t smallest_lookup = (d->comp_width == 4) ? split_bytes : bitmap_bytes;
+  auto uni_for = [&](uint32_t items) { return up(std::max<uint64_t>((uint64_t)items * 16 + NT * 12, sort_bytes)); };
+  const uint64_t smallest_lookup = (d->comp_width == 4) ? split_bytes : bitmap_bytes;
   if (!std::getenv("SGPU_ITEMS_MAX")) {
     const uint32_t want = items_max;
     if (dense_ok)   // the dense table is worth smaller rounds (down to 512 items)
@@ -511,7 +666,7 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
       while (items_max > 256 && o + smallest_lookup + uni_for(items_max) > budget) items_max -= 128;
     }
   }
-  const uint32_t min_uni = uni_for(items_max);
+  const uint64_t min_uni = uni_for(items_max);
   const bool dense = dense_ok && (o + dense_bytes + min_uni <= budget || env_u32("SGPU_FORCE_DENSE", 0));
   // large vocabularies: bits + 16-bit ranks (6 B per 32 ids) when the packed table (8 B) would
   // cost the second workgroup per CU
@@ -519,25 +674,25 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
                      (o + bitmap_bytes + min_uni > budget || env_u32("SGPU_FORCE_SPLIT", 0)) &&
                      !env_u32("SGPU_NO_SPLIT", 0);
   const uint32_t lookup = dense ? LK_DENSE : (split ? LK_SPLIT : LK_PACKED);
-  const uint32_t lookup_bytes = mode == MODE_DOTS ? 0u : (dense ? dense_bytes : (split ? split_bytes : bitmap_bytes));
-  L.q_bits = o;
-  L.q_rank = o + (split ? split_bits : lookup_bytes);
+  const uint64_t lookup_bytes = mode == MODE_DOTS ? 0u : (dense ? dense_bytes : (split ? split_bytes : bitmap_bytes));
+  L.q_bits = (uint32_t)o;
+  L.q_rank = (uint32_t)(o + (split ? split_bits : lookup_bytes));
   o += lookup_bytes;
-  L.uni = o;
-  const uint32_t uni = min_uni;
+  L.uni = (uint32_t)std::min<uint64_t>(o, 0xffffffffu);
+  const uint64_t uni = min_uni;
   o += uni;
   L.qc = qc;
   L.qn = qn;
   a->lookup = lookup;
-  L.total = o;
   if (o > lds_limit)
     return fail(SGPU_ELIMIT,
-                "query needs %u bytes of LDS (dots %u blocks, %u-word bitmap, sort %u B) > %u available; "
+                "query needs %llu bytes of LDS (dots %u blocks, %u-word bitmap, sort %llu B) > %llu available; "
                 "lower query_cut / use first_sorted=0 / rebuild with a smaller centroid_fraction",
-                o, dots_cap, words, sort_bytes, lds_limit);
+                (unsigned long long)o, dots_cap, words, (unsigned long long)sort_bytes, (unsigned long long)lds_limit);
+  L.total = (uint32_t)o;
   a->L = L;
   a->p.k = sp.k;
-  a->p.query_cut = qc;
+  a->p.query_cut = cut;
   a->p.heap_factor = sp.heap_factor;
   a->p.first_sorted = sp.first_sorted != 0;
   a->p.mode = mode == MODE_COUNTED ? (uint32_t)MODE_SEARCH : mode;
@@ -551,11 +706,11 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   a->ix = d->view;
   a->comp_width = d->comp_width;
   a->block = NT;
-  a->lds_bytes = o;
+  a->lds_bytes = (uint32_t)o;
   if (env_u32("SGPU_DEBUG", 0))
-    std::fprintf(stderr, "sgpu configure: NT %u lookup %u items_max %u dots_cap %u uni %u lds %u\n", NT, lookup,
-                 items_max, dots_cap, uni, o);
-  a->stream = d->stream;
+    std::fprintf(stderr, "sgpu configure: NT %u lookup %u items_max %u dots_cap %u uni %llu lds %llu\n", NT, lookup,
+                 items_max, dots_cap, (unsigned long long)uni, (unsigned long long)o);
+  a->stream = lane->stream;
   a->qb.q_off = b->q_off;
   a->qb.q_comp = b->q_comp;
   a->qb.q_val = b->q_val;
@@ -564,13 +719,23 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
   a->qb.out_scores = b->out_scores;
   a->qb.out_ids = b->out_ids;
   a->qb.out_n = b->out_n;
-  a->qb.q_order = d_order;
+  a->qb.q_order = nullptr;
+  if (pl && !env_u32("SGPU_NO_LPT", 0) && b->nq) {
+    // the processing order lives in the batch's own device buffer (no allocation on the path)
+    if (b->order_cut != cut) {
+      if (b->order_cut != 0xffffffffu) HIP_TRY(hipStreamSynchronize(lane->stream));   // the staging copy may be in flight
+      std::memcpy(b->h_order, pl->order.data(), (size_t)b->nq * 4);
+      HIP_TRY(hipMemcpyAsync(b->q_order, b->h_order, (size_t)b->nq * 4, hipMemcpyHostToDevice, lane->stream));
+      b->order_cut = cut;
+    }
+    a->qb.q_order = b->q_order;
+  }
   a->qb.out_stats = mode != MODE_DOTS ? b->out_stats : nullptr;
   // occupancy of this kernel variant at this LDS size: queried once, then remembered
   int per_cu = 0;
   {
     const uint64_t key = ((uint64_t)a->comp_width << 56) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
-                         ((uint64_t)(a->p.k <= 64 ? 1 : (a->p.k <= 128 ? 2 : 16)) << 28) | (uint64_t)(a->lds_bytes >> 4);
+                         ((uint64_t)heap_variant(a->p.k) << 28) | (uint64_t)(a->lds_bytes >> 4);
     auto it = d->occupancy.find(key);
     if (it == d->occupancy.end()) {
       HIP_TRY(occupancy_search(*a, &per_cu));
@@ -579,115 +744,137 @@ static sgpu_status configure(DeviceIndex* d, sgpu_batch* b, const sgpu_search_pa
       per_cu = it->second;
     }
   }
-  if (per_cu < 1) return fail(SGPU_ELIMIT, "the search kernel does not fit on a CU with %u bytes of LDS", o);
+  if (per_cu < 1) return fail(SGPU_ELIMIT, "the search kernel does not fit on a CU with %llu bytes of LDS", (unsigned long long)o);
   const uint32_t cap = env_u32("SGPU_WG_PER_CU", 0);
   if (cap && (uint32_t)per_cu > cap) per_cu = (int)cap;
   uint32_t grid = d->n_cu * (uint32_t)per_cu;
   grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
   a->grid = grid;
-  // visited bitmaps: one per resident workgroup
-  if (a->p.use_bitmap && d->bitmaps_slots < grid) {
-    if (d->bitmaps) (void)hipFree(d->bitmaps);
-    d->bitmaps = nullptr;
-    d->bitmaps_slots = 0;
-    const uint32_t slots = std::max<uint32_t>(grid, d->n_cu * (uint32_t)per_cu);
-    const size_t bytes = (size_t)slots * std::max<uint32_t>(d->view.n_bitmap_words, 1) * 4;
-    if (hipMalloc((void**)&d->bitmaps, bytes) != hipSuccess)
-      return fail(SGPU_ENOMEM, "hipMalloc of %zu bytes of visited bitmaps failed", bytes);
-    HIP_TRY(hipMemsetAsync(d->bitmaps, 0, bytes, d->stream));
-    d->bitmaps_slots = slots;
+  // visited bitmaps: one per resident workgroup (counted pass; main lane only)
+  a->bitmaps = nullptr;
+  if (a->p.use_bitmap) {
+    if (lane != &d->main) return fail(SGPU_EINVAL, "the counted pass runs on the index's main lane only");
+    if (d->bitmaps_slots < grid) {
+      if (d->bitmaps) {
+        HIP_TRY(hipStreamSynchronize(lane->stream));
+        (void)hipFree(d->bitmaps);
+      }
+      d->bitmaps = nullptr;
+      d->bitmaps_slots = 0;
+      const uint32_t slots = std::max<uint32_t>(grid, d->n_cu * (uint32_t)per_cu);
+      const size_t bytes = (size_t)slots * std::max<uint32_t>(d->view.n_bitmap_words, 1) * 4;
+      if (hipMalloc((void**)&d->bitmaps, bytes) != hipSuccess)
+        return fail(SGPU_ENOMEM, "hipMalloc of %zu bytes of visited bitmaps failed", bytes);
+      HIP_TRY(hipMemsetAsync(d->bitmaps, 0, bytes, lane->stream));
+      d->bitmaps_slots = slots;
+    }
+    a->bitmaps = d->bitmaps;
   }
-  a->queue = d->queue;
-  a->bitmaps = d->bitmaps;
+  a->queue = lane->queue;
   return SGPU_OK;
 }
 
-static void drain_events(DeviceIndex* d) {   // stream must be idle
-  for (int i = 0; i < d->ev_pending; ++i) {
+static void drain_events(Lane* l) {   // stream must be idle
+  for (int i = 0; i < l->ev_pending; ++i) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, d->ev0[i], d->ev1[i]) == hipSuccess) {
-      d->sum_ms += ms;
-      d->n_timed += 1;
+    if (hipEventElapsedTime(&ms, l->ev0[i], l->ev1[i]) == hipSuccess) {
+      l->sum_ms += ms;
+      l->n_timed += 1;
     }
   }
-  d->ev_pending = 0;
+  l->ev_pending = 0;
 }
 
-sgpu_status batch_run(DeviceIndex* d, sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode, int sync,
-                      sgpu_launch_stats* stats) {
+// Enqueues one pass on `lane` (the index's main lane when null).
+sgpu_status batch_run(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode,
+                      int sync, sgpu_launch_stats* stats) {
   if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
-  if (!b || b->device != d->device) return fail(SGPU_EINVAL, "batch does not belong to this index's device");
-  std::lock_guard<std::mutex> lock(d->mu);
+  if (!b || b->owner != d) return fail(SGPU_EINVAL, "batch does not belong to this index replica");
+  if (!lane) lane = &d->main;
   HIP_TRY(hipSetDevice(d->device));
   if (b->nq == 0) {
     if (stats) *stats = sgpu_launch_stats{};
     return SGPU_OK;
   }
-  LaunchArgs a{};
-  sgpu_status st = configure(d, b, sp, mode, &a);
-  if (st != SGPU_OK) return st;
-  if (d->ev_pending == DeviceIndex::kEvents) {
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    drain_events(d);
+  {
+    // configuration touches state shared by the lanes (occupancy cache, bitmaps); a main-lane
+    // launch also owns the main lane's event ring
+    std::lock_guard<std::mutex> lock(d->mu);
+    LaunchArgs a{};
+    sgpu_status st = configure(d, lane, b, sp, mode, &a);
+    if (st != SGPU_OK) return st;
+    if (lane->ev_pending == (int)lane->ev0.size()) {
+      HIP_TRY(hipStreamSynchronize(lane->stream));
+      drain_events(lane);
+    }
+    HIP_TRY(hipMemsetAsync(lane->queue, 0, 4, lane->stream));
+    if (a.qb.out_stats) HIP_TRY(hipMemsetAsync(b->out_stats, 0, (size_t)b->nq * STATS_WORDS * 4, lane->stream));
+    const int e = lane->ev_pending++;
+    HIP_TRY(hipEventRecord(lane->ev0[e], lane->stream));
+    HIP_TRY(launch_search(a));
+    HIP_TRY(hipEventRecord(lane->ev1[e], lane->stream));
+    lane->last.n_queries = b->nq;
+    lane->last.grid = a.grid;
+    lane->last.block = a.block;
+    lane->last.lds_bytes = a.lds_bytes;
   }
-  HIP_TRY(hipMemsetAsync(d->queue, 0, 4, d->stream));
-  if (a.qb.out_stats) HIP_TRY(hipMemsetAsync(b->out_stats, 0, (size_t)b->nq * STATS_WORDS * 4, d->stream));
-  const int e = d->ev_pending++;
-  HIP_TRY(hipEventRecord(d->ev0[e], d->stream));
-  HIP_TRY(launch_search(a));
-  HIP_TRY(hipEventRecord(d->ev1[e], d->stream));
-  d->last.n_queries = b->nq;
-  d->last.grid = a.grid;
-  d->last.block = a.block;
-  d->last.lds_bytes = a.lds_bytes;
   if (sync) {
-    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(hipStreamSynchronize(lane->stream));
+    std::lock_guard<std::mutex> lock(d->mu);
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, d->ev0[e], d->ev1[e]));
-    drain_events(d);
-    d->last.kernel_ms = ms;
-    if (stats) *stats = d->last;
+    HIP_TRY(hipEventElapsedTime(&ms, lane->ev0[lane->ev_pending - 1], lane->ev1[lane->ev_pending - 1]));
+    drain_events(lane);
+    lane->last.kernel_ms = ms;
+    if (stats) *stats = lane->last;
   }
   return SGPU_OK;
 }
 
-// Waits for everything enqueued; stats->kernel_ms = mean kernel duration since the last sync.
+// Waits for everything enqueued on the main lane; stats->kernel_ms = mean kernel duration since the last sync.
 sgpu_status batch_sync(DeviceIndex* d, sgpu_launch_stats* stats) {
   if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device");
-  std::lock_guard<std::mutex> lock(d->mu);
+  Lane* l = &d->main;
   HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipStreamSynchronize(d->stream));
-  drain_events(d);
+  HIP_TRY(hipStreamSynchronize(l->stream));
+  std::lock_guard<std::mutex> lock(d->mu);
+  drain_events(l);
   if (stats) {
-    *stats = d->last;
-    stats->kernel_ms = d->n_timed ? (float)(d->sum_ms / d->n_timed) : 0.0f;
+    *stats = l->last;
+    stats->kernel_ms = l->n_timed ? (float)(l->sum_ms / l->n_timed) : 0.0f;
   }
-  d->sum_ms = 0;
-  d->n_timed = 0;
+  l->sum_ms = 0;
+  l->n_timed = 0;
   return SGPU_OK;
 }
 
-sgpu_status batch_fetch(DeviceIndex* d, sgpu_batch* b, uint32_t k, float* out_scores, uint64_t* out_ids,
+sgpu_status batch_fetch(DeviceIndex* d, Lane* lane, sgpu_batch* b, uint32_t k, float* out_scores, uint64_t* out_ids,
                         uint32_t* out_n) {
   if (!d || !b) return fail(SGPU_EINVAL, "null index/batch");
   if (k == 0 || k > b->k_max) return fail(SGPU_EINVAL, "k out of range for this batch");
-  std::lock_guard<std::mutex> lock(d->mu);
+  if (!lane) lane = &d->main;
   HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipStreamSynchronize(d->stream));
-  if (b->nq == 0) return SGPU_OK;
-  HIP_TRY(hipMemcpy2D(out_scores, (size_t)k * 4, b->out_scores, (size_t)b->k_max * 4, (size_t)k * 4, b->nq,
-                      hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy2D(out_ids, (size_t)k * 8, b->out_ids, (size_t)b->k_max * 8, (size_t)k * 8, b->nq,
-                      hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(out_n, b->out_n, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
+  if (b->nq == 0) {
+    HIP_TRY(hipStreamSynchronize(lane->stream));
+    return SGPU_OK;
+  }
+  if (k == b->k_max) {
+    HIP_TRY(hipMemcpyAsync(out_scores, b->out_scores, (size_t)b->nq * k * 4, hipMemcpyDeviceToHost, lane->stream));
+    HIP_TRY(hipMemcpyAsync(out_ids, b->out_ids, (size_t)b->nq * k * 8, hipMemcpyDeviceToHost, lane->stream));
+  } else {
+    HIP_TRY(hipMemcpy2DAsync(out_scores, (size_t)k * 4, b->out_scores, (size_t)b->k_max * 4, (size_t)k * 4, b->nq,
+                             hipMemcpyDeviceToHost, lane->stream));
+    HIP_TRY(hipMemcpy2DAsync(out_ids, (size_t)k * 8, b->out_ids, (size_t)b->k_max * 8, (size_t)k * 8, b->nq,
+                             hipMemcpyDeviceToHost, lane->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(out_n, b->out_n, (size_t)b->nq * 4, hipMemcpyDeviceToHost, lane->stream));
+  HIP_TRY(hipStreamSynchronize(lane->stream));
   return SGPU_OK;
 }
 
 sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out) {
   if (!d || !b || !out) return fail(SGPU_EINVAL, "null index/batch/out");
-  std::lock_guard<std::mutex> lock(d->mu);
   HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipStreamSynchronize(d->stream));
+  HIP_TRY(hipStreamSynchronize(d->main.stream));
   if (b->nq) HIP_TRY(hipMemcpy(out, b->out_stats, (size_t)b->nq * STATS_WORDS * 4, hipMemcpyDeviceToHost));
   return SGPU_OK;
 }
@@ -707,15 +894,14 @@ sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list,
   // (KParams::target_list, carried here in query_cut), and dumps the accumulators.
   const uint64_t q_off[2] = {0, nnz};
   sgpu_batch* b = nullptr;
-  sgpu_status st = batch_create(d, h.dim, q_off, comps, vals, 1, 1, &b);
+  sgpu_status st = batch_create(d, &d->main, h.dim, q_off, comps, vals, 1, 1, &b);
   if (st != SGPU_OK) return st;
   sgpu_search_params sp{};
   sp.k = 1;
   sp.query_cut = list;   // MODE_DOTS: carries the target list id
   sp.heap_factor = 0;
-  st = batch_run(d, b, sp, MODE_DOTS, 1, nullptr);
+  st = batch_run(d, nullptr, b, sp, MODE_DOTS, 1, nullptr);
   if (st == SGPU_OK) {
-    std::lock_guard<std::mutex> lock(d->mu);
     if (hipMemcpy(out_dots, b->out_scores, (size_t)nb * 4, hipMemcpyDeviceToHost) != hipSuccess)
       st = fail(SGPU_EDEVICE, "hipMemcpy of summary dots failed");
   }
@@ -729,9 +915,9 @@ sgpu_status device_index_set_knn(DeviceIndex* d, const std::vector<uint32_t>& kn
   if (!d) return SGPU_OK;
   std::lock_guard<std::mutex> lock(d->mu);
   HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipStreamSynchronize(d->stream));
+  HIP_TRY(hipDeviceSynchronize());
   if (d->view.knn) {   // drop the previous graph's device copy
-    auto it = std::find(d->allocs.begin(), d->allocs.end(), (void*)d->view.knn);
+    auto it = std::find_if(d->allocs.begin(), d->allocs.end(), [&](const Alloc& a) { return a.p == (void*)d->view.knn; });
     if (it != d->allocs.end()) d->allocs.erase(it);
     (void)hipFree((void*)d->view.knn);
     d->bytes -= std::min<uint64_t>(d->bytes, d->view.knn_total * 4);
@@ -786,13 +972,13 @@ sgpu_status build_knn_on_device(DeviceIndex* d, HostIndex& h, uint32_t nknn) {
       q_val[i - e0] = f16_to_f32(h.fwd_vals[i]);
     }
     sgpu_batch* b = nullptr;
-    st = batch_create(d, h.dim, q_off.data(), q_comp.data(), q_val.data(), nq, k, &b);
+    st = batch_create(d, &d->main, h.dim, q_off.data(), q_comp.data(), q_val.data(), nq, k, &b);
     if (st != SGPU_OK) return st;
-    st = batch_run(d, b, sp, MODE_SEARCH, 1, nullptr);
+    st = batch_run(d, nullptr, b, sp, MODE_SEARCH, 1, nullptr);
     sc.resize((size_t)nq * k);
     ids.resize((size_t)nq * k);
     n.resize(nq);
-    if (st == SGPU_OK) st = batch_fetch(d, b, k, sc.data(), ids.data(), n.data());
+    if (st == SGPU_OK) st = batch_fetch(d, nullptr, b, k, sc.data(), ids.data(), n.data());
     batch_free(b);
     if (st != SGPU_OK) return st;
     for (uint32_t q = 0; q < nq; ++q) {

@@ -85,4 +85,7 @@ struct LaunchArgs {
 
 hipError_t launch_search(const LaunchArgs& a);
 
+// Registers of wavefront 0 per heap entry array (RegHeap<KR>): the kernel variant that serves k.
+inline uint32_t heap_variant(uint32_t k) { return k <= 64 ? 1u : (k <= 128 ? 2u : (k <= 256 ? 4u : (k <= 512 ? 8u : 16u))); }
+
 }  // namespace sgpu

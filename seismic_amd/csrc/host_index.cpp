@@ -8,6 +8,7 @@
 
 #include <cerrno>
 #include <cstdlib>
+#include <exception>
 
 namespace sgpu {
 
@@ -147,13 +148,15 @@ static bool rd(FILE* f, std::vector<T>& v, uint64_t n) {
 sgpu_status host_index_save(const HostIndex& ix, const char* path) {
   FILE* f = fopen(path, "wb");
   if (!f) return fail(SGPU_EIO, "cannot open %s for writing: %s", path, strerror(errno));
-  uint64_t hdr[10] = {ix.comp_width, ix.n_docs,      ix.dim,      ix.nnz(), ix.n_blocks(),
-                      ix.n_postings(), ix.n_rows(), ix.n_entries(), 0,        0};
+  // hdr[8] = neighbours per document, hdr[9] = total neighbour ids of the kNN graph (0, 0 = no graph);
+  // the reference serialises InvertedIndexBase{.., knn} in one file too (src/inverted_index.rs:39-52)
+  uint64_t hdr[10] = {ix.comp_width,   ix.n_docs,   ix.dim,         ix.nnz(),   ix.n_blocks(),
+                      ix.n_postings(), ix.n_rows(), ix.n_entries(), ix.knn_dim, ix.knn.size()};
   bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, 8, 10, f) == 10 && wr(f, ix.fwd_offsets) &&
             wr(f, ix.fwd_comps) && wr(f, ix.fwd_vals) && wr(f, ix.list_block_start) &&
             wr(f, ix.block_post_start) && wr(f, ix.post_doc) && wr(f, ix.blk_min) && wr(f, ix.blk_quant) &&
             wr(f, ix.list_row_start) && wr(f, ix.row_comp) && wr(f, ix.row_ptr) && wr(f, ix.sum_bid) &&
-            wr(f, ix.sum_code);
+            wr(f, ix.sum_code) && wr(f, ix.knn);
   ok = (fclose(f) == 0) && ok;
   if (!ok) return fail(SGPU_EIO, "short write to %s", path);
   return SGPU_OK;
@@ -172,20 +175,46 @@ sgpu_status host_index_load(const char* path, HostIndex* out) {
   h.comp_width = (uint32_t)hdr[0];
   h.n_docs = hdr[1];
   h.dim = hdr[2];
-  const uint64_t nnz = hdr[3], nb = hdr[4], np = hdr[5], nr = hdr[6], ne = hdr[7];
+  const uint64_t nnz = hdr[3], nb = hdr[4], np = hdr[5], nr = hdr[6], ne = hdr[7], knn_dim = hdr[8], nk = hdr[9];
   bool ok = (h.comp_width == 2 || h.comp_width == 4);
+  // the header is untrusted: the counts must add up to the file's size before anything is resized
+  if (ok) {
+    const uint64_t lim = 1ull << 48;
+    ok = h.n_docs < lim && h.dim < lim && nnz < lim && nb < lim && np < lim && nr < lim && ne < lim && nk < lim &&
+         knn_dim <= 0xffffffffull && ((knn_dim == 0) == (nk == 0));
+    long pos = ftell(f);
+    ok = ok && pos >= 0 && fseek(f, 0, SEEK_END) == 0;
+    const long end = ok ? ftell(f) : -1;
+    ok = ok && end >= 0 && fseek(f, pos, SEEK_SET) == 0;
+    if (ok) {
+      const uint64_t cw = h.comp_width;
+      const uint64_t need = 8 * (h.n_docs + 1) + nnz * cw + nnz * 2 + 8 * (h.dim + 1) + 8 * (nb + 1) + 4 * np + 8 * nb +
+                            8 * (h.dim + 1) + nr * cw + 8 * (nr + 1) + 3 * ne + 4 * nk;
+      ok = (uint64_t)(end - pos) == need;
+    }
+  }
+  if (!ok) {
+    fclose(f);
+    return fail(SGPU_EIO, "corrupt index file %s (header does not match the file size)", path);
+  }
   try {
-    ok = ok && rd(f, h.fwd_offsets, h.n_docs + 1) && rd(f, h.fwd_comps, nnz * h.comp_width) &&
+    ok = rd(f, h.fwd_offsets, h.n_docs + 1) && rd(f, h.fwd_comps, nnz * h.comp_width) &&
          rd(f, h.fwd_vals, nnz) && rd(f, h.list_block_start, h.dim + 1) && rd(f, h.block_post_start, nb + 1) &&
          rd(f, h.post_doc, np) && rd(f, h.blk_min, nb) && rd(f, h.blk_quant, nb) &&
          rd(f, h.list_row_start, h.dim + 1) && rd(f, h.row_comp, nr * h.comp_width) && rd(f, h.row_ptr, nr + 1) &&
-         rd(f, h.sum_bid, ne) && rd(f, h.sum_code, ne);
+         rd(f, h.sum_bid, ne) && rd(f, h.sum_code, ne) && rd(f, h.knn, nk);
   } catch (const std::bad_alloc&) {
     fclose(f);
     return fail(SGPU_ENOMEM, "out of host memory loading %s", path);
+  } catch (const std::exception& e) {
+    fclose(f);
+    return fail(SGPU_EIO, "cannot load %s: %s", path, e.what());
   }
   fclose(f);
   if (!ok) return fail(SGPU_EIO, "truncated or corrupt index file %s", path);
+  h.knn_dim = (uint32_t)knn_dim;
+  for (uint32_t id : h.knn)
+    if (id >= h.n_docs) return fail(SGPU_EIO, "corrupt index file %s: kNN neighbour id >= n_docs", path);
   sgpu_index_desc d;
   h.fill_desc(&d);
   return validate_desc(d);

@@ -64,5 +64,6 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
 // the opaque handle of the C ABI
 struct sgpu_index {
   sgpu::HostIndex host;
-  sgpu::DeviceIndex* dev = nullptr;
+  std::vector<sgpu::DeviceIndex*> replicas;   // one per device the index was uploaded to
+  sgpu::DeviceIndex* dev = nullptr;           // replicas[0] (null before upload)
 };

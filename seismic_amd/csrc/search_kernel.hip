@@ -1127,7 +1127,10 @@ __global__ __launch_bounds__(NT, SGPU_WAVES_PER_EU) void seismic_search_kernel(D
         while (pos < nb) {
           // (a) filter the remaining blocks against the current threshold
           const uint32_t hlen = s.st[ST_HLEN];
-          const bool full = hlen == p.k;
+          // A block may be dropped here against a threshold that is older than the one the replay
+          // will use only because heap_factor * threshold never decreases - true for
+          // heap_factor >= 0. A negative factor prunes nothing here; the replay decides alone.
+          const bool full = hlen == p.k && p.heap_factor >= 0.0f;
           const float cut = __fmul_rn(p.heap_factor, __uint_as_float(s.st[ST_THR]));
           const uint32_t remaining = nb - pos;
           uint32_t R = (remaining + NT - 1) / NT;
@@ -1387,9 +1390,13 @@ static hipError_t run_one(const LaunchArgs& a, int* occupancy) {
 template <typename CT, int NT, int LK>
 static hipError_t run_kr(const LaunchArgs& a, int* occ) {
   const uint32_t k = a.p.k;
-  if (k <= 64) return run_one<CT, NT, 1, LK>(a, occ);
-  if (k <= 128) return run_one<CT, NT, 2, LK>(a, occ);
-  return run_one<CT, NT, 16, LK>(a, occ);
+  switch (heap_variant(k)) {
+    case 1: return run_one<CT, NT, 1, LK>(a, occ);
+    case 2: return run_one<CT, NT, 2, LK>(a, occ);
+    case 4: return run_one<CT, NT, 4, LK>(a, occ);
+    case 8: return run_one<CT, NT, 8, LK>(a, occ);
+    default: return run_one<CT, NT, 16, LK>(a, occ);
+  }
 }
 
 static hipError_t run_any(const LaunchArgs& a, int* occ) {

@@ -34,7 +34,6 @@ import gzip
 import io
 import json
 import os
-import struct
 import tarfile
 
 import numpy as np
@@ -88,36 +87,50 @@ def read_jsonl(path):
 
 def read_inner_format(path, comp_dtype=np.uint32):
     """Seismic's inner binary format (scripts/convert_json_to_inner_format.py:10-27):
-    u32 n_vecs; per vector: u32 n, n x u32 components (sorted), n x f32 values; little endian."""
+    u32 n_vecs; per vector: u32 n, n x u32 components (sorted), n x f32 values; little endian.
+    Parsed by the native library (sgpu_dataset_read): an 8.8M-document file reads at disk speed."""
     try:
-        raw = np.fromfile(path, dtype=np.uint8)
-    except OSError as e:
+        return _native.read_inner_format(path)
+    except _native.SeismicHipError as e:
         raise IOError(str(e))
-    n_vecs = struct.unpack_from("<I", raw, 0)[0]
-    off = np.zeros(n_vecs + 1, np.uint64)
-    comps, vals = [], []
-    p = 4
-    for i in range(n_vecs):
-        n = struct.unpack_from("<I", raw, p)[0]
-        p += 4
-        comps.append(raw[p:p + 4 * n].view("<u4"))
-        p += 4 * n
-        vals.append(raw[p:p + 4 * n].view("<f4"))
-        p += 4 * n
-        off[i + 1] = off[i] + n
-    c = np.concatenate(comps).astype(np.uint32) if comps else np.zeros(0, np.uint32)
-    v = np.concatenate(vals).astype(np.float32) if vals else np.zeros(0, np.float32)
-    return off, c, v
 
 
 def write_inner_format(path, off, comps, vals):
-    with open(path, "wb") as f:
-        f.write(struct.pack("<I", len(off) - 1))
-        for i in range(len(off) - 1):
-            s, e = int(off[i]), int(off[i + 1])
-            f.write(struct.pack("<I", e - s))
-            f.write(np.asarray(comps[s:e], "<u4").tobytes())
-            f.write(np.asarray(vals[s:e], "<f4").tobytes())
+    try:
+        _native.write_inner_format(path, off, comps, vals)
+    except _native.SeismicHipError as e:
+        raise IOError(str(e))
+
+
+def write_results_tsv(path, scores, ids, n):
+    """`query_index \\t doc_id \\t rank \\t score` per result, the dump of the reference's
+    perf_inverted_index (src/bin/perf_inverted_index.rs:223-235)."""
+    try:
+        _native.write_results_tsv(path, scores, ids, n)
+    except _native.SeismicHipError as e:
+        raise IOError(str(e))
+
+
+def read_results_tsv(path):
+    """-> {query_id: [doc_id, ...]} of a results / groundtruth TSV (same four columns)."""
+    out = {}
+    try:
+        with open(path, "r", encoding="utf-8") as f:
+            for line in f:
+                if line.strip():
+                    q, d = line.split("\t")[:2]
+                    out.setdefault(int(q), []).append(int(d))
+    except (OSError, ValueError) as e:
+        raise IOError("Failed to read %s: %s" % (path, e))
+    return out
+
+
+def accuracy(results, groundtruth):
+    """compute_accuracy of the reference's scripts/run_experiments.py:287-309: per query the size of
+    the intersection of the two doc-id sets, summed, over the number of ground-truth rows."""
+    total = sum(len(v) for v in groundtruth.values())
+    hit = sum(len(set(v) & set(results.get(q, ()))) for q, v in groundtruth.items())
+    return hit / total if total else 0.0
 
 
 def _token_map(vecs, given=None):
@@ -354,8 +367,9 @@ class _IndexBase:
         print("\tPosting Lists: %d Bytes" % (packed + boffs + summ))
         print("\t  packed_postings: %d Bytes\n\t  block_offsets: %d Bytes\n\t  summaries: %d Bytes"
               % (packed, boffs, summ))
-        print("\tKnn: 0 Bytes")
-        print("\tTotal: %d Bytes" % (fwd + packed + boffs + summ))
+        knn = 4 * len(self._ix.get_knn()[0])
+        print("\tKnn: %d Bytes" % knn)
+        print("\tTotal: %d Bytes" % (fwd + packed + boffs + summ + knn))
         print("\tHBM resident: %d Bytes" % self._ix.device_bytes())
 
     def get_doc_text(self, doc_id):

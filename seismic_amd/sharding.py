@@ -22,21 +22,13 @@ def shard_csr(q_off, comps, vals, world, rank):
     return (q_off[lo:hi + 1] - q_off[lo]).astype(np.uint64), np.asarray(comps)[s:e], np.asarray(vals)[s:e]
 
 
-def batch_search_sharded(search_fn, q_off, comps, vals, k, group=None):
-    """Every rank searches its shard with `search_fn(q_off, comps, vals) -> (scores[nq,k], ids[nq,k], n[nq])`
-    and all ranks receive the full result in input order. Uses torch.distributed when it is
-    initialised (backend nccl == RCCL on GPUs, gloo on CPU); otherwise a single shard."""
-    try:
-        import torch
-        import torch.distributed as dist
-        active = dist.is_available() and dist.is_initialized()
-    except ImportError:
-        active = False
-    if not active:
-        return search_fn(np.asarray(q_off, np.uint64), comps, vals)
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    sc, ids, n = search_fn(*shard_csr(q_off, comps, vals, world, rank))
-    nq = len(q_off) - 1
+def gather_rows(sc, ids, n, nq, group=None):
+    """All ranks contribute the result rows of their contiguous shard of an `nq`-query batch and
+    receive the full (scores[nq,k], ids[nq,k], n[nq]) in input order. This gather of result rows
+    is the only communication of the multi-GPU path (nccl == RCCL on GPUs, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
     sizes = [shard_bounds(nq, world, r)[1] - shard_bounds(nq, world, r)[0] for r in range(world)]
     mx = max(sizes) if sizes else 0
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
@@ -53,3 +45,19 @@ def batch_search_sharded(search_fn, q_off, comps, vals, k, group=None):
     return (gather(np.ascontiguousarray(sc, np.float32), np.float32),
             gather(np.ascontiguousarray(ids, np.uint64).view(np.int64), np.int64).view(np.uint64),
             gather(np.ascontiguousarray(n, np.uint32).view(np.int32), np.int32).view(np.uint32))
+
+
+def batch_search_sharded(search_fn, q_off, comps, vals, k, group=None):
+    """Every rank searches its shard with `search_fn(q_off, comps, vals) -> (scores[nq,k], ids[nq,k], n[nq])`
+    and all ranks receive the full result in input order. Uses torch.distributed when it is
+    initialised (backend nccl == RCCL on GPUs, gloo on CPU); otherwise a single shard."""
+    try:
+        import torch.distributed as dist
+        active = dist.is_available() and dist.is_initialized()
+    except ImportError:
+        active = False
+    if not active:
+        return search_fn(np.asarray(q_off, np.uint64), comps, vals)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    sc, ids, n = search_fn(*shard_csr(q_off, comps, vals, world, rank))
+    return gather_rows(sc, ids, n, len(q_off) - 1, group)

@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     L = ctypes.CDLL(_native.LIB_PATH)
     missing = [n for n in sorted(names) if not hasattr(L, n)]
     assert not missing, missing
-    assert L.sgpu_abi_version() == 1
+    assert L.sgpu_abi_version() == 2
 
 
 def test_struct_layouts_match_header_sizes():
@@ -191,3 +191,47 @@ def test_oracle_knn_restatement_properties():
                 assert np.float32(orc.score_doc(ix.desc, int(d_), c, v)) == s_
     finally:
         orc.knn_attach(None, 0)
+
+
+def test_index_file_keeps_the_knn_graph_and_rejects_corrupt_files(tmp_path):
+    """host side of sgpu_index_save/load: the kNN graph is part of the file (the reference serialises
+    InvertedIndexBase{.., knn}); a header that does not add up to the file size is an error, never a crash."""
+    dim = 64
+    off, comps, vals = random_dataset(81, 300, dim)
+    ix = _native.NativeIndex.build(2, dim, off, comps, vals, BuildConfig.defaults(n_postings=20))
+    rng = np.random.default_rng(5)
+    nb = rng.integers(0, 300, 300 * 4).astype(np.uint32)
+    ix.set_knn(nb, 4)                      # no device: host side only
+    p = str(tmp_path / "a.idx")
+    ix.save(p)
+    ix2 = _native.NativeIndex.load(p)
+    got, kd = ix2.get_knn()
+    assert kd == 4 and np.array_equal(got, nb)
+    from util import desc_equal
+    desc_equal(ix.desc, ix2.desc)
+    raw = bytearray(open(p, "rb").read())
+    for name, edit in [("truncated", lambda b: b[:len(b) - 7]),
+                       ("huge count", lambda b: b[:8 + 8 * 3] + (2 ** 62).to_bytes(8, "little") + b[8 + 8 * 4:]),
+                       ("bad magic", lambda b: b"XXXXXXXX" + b[8:]),
+                       ("knn id out of range", lambda b: b[:len(b) - 4] + (10 ** 6).to_bytes(4, "little"))]:
+        q = str(tmp_path / "bad.idx")
+        open(q, "wb").write(bytes(edit(raw)))
+        with pytest.raises(_native.SeismicHipError) as e:
+            _native.NativeIndex.load(q)
+        assert e.value.status == 4, name   # SGPU_EIO
+
+
+def test_results_tsv_and_accuracy(tmp_path):
+    """perf_inverted_index's result dump (src/bin/perf_inverted_index.rs:223-235) and compute_accuracy
+    of scripts/run_experiments.py:287-309."""
+    from seismic_amd.index import accuracy, read_results_tsv, write_results_tsv
+    sc = np.array([[3.5, 2.25, 0.0], [1.0, 0.0, 0.0]], np.float32)
+    ids = np.array([[7, 3, 0], [11, 0, 0]], np.uint64)
+    n = np.array([2, 1], np.uint32)
+    p = str(tmp_path / "res.tsv")
+    write_results_tsv(p, sc, ids, n)
+    assert open(p).read() == "0\t7\t1\t3.5\n0\t3\t2\t2.25\n1\t11\t1\t1\n"
+    res = read_results_tsv(p)
+    assert res == {0: [7, 3], 1: [11]}
+    gt = {0: [7, 9], 1: [11], 2: [5]}
+    assert accuracy(res, gt) == pytest.approx(2 / 4)

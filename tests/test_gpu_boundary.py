@@ -1,0 +1,165 @@
+"""Drop-in boundary on the GPU: concurrency, replicas, query-time edge semantics, the raw classes.
+Run with `-m gpu` on an MI355X."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import orc
+import seismic_amd
+from seismic_amd import _native
+from seismic_amd._abi import BuildConfig
+from util import random_dataset, random_queries
+
+pytestmark = pytest.mark.gpu
+
+
+def _index(seed=61, n_docs=5000, dim=400):
+    off, comps, vals = random_dataset(seed, n_docs, dim, nnz_lo=8, nnz_hi=150)
+    ix = _native.NativeIndex.build(2, dim, off, comps, vals,
+                                   BuildConfig.defaults(n_postings=120, centroid_fraction=0.2, summary_energy=0.5,
+                                                        max_fraction=6.0))
+    return ix, dim
+
+
+def _same(gpu, cpu):
+    gs, gi, gn = gpu
+    cs, ci, cn = cpu
+    assert np.array_equal(gn, cn)
+    for q in range(len(gn)):
+        n = int(gn[q])
+        assert np.array_equal(gi[q, :n], ci[q, :n]), q
+        assert np.array_equal(gs[q, :n].view(np.uint32), cs[q, :n].view(np.uint32)), q
+
+
+def test_query_cut_zero_selects_no_list():
+    """k_largest_by(0) selects nothing: the reference returns an empty result (src/inverted_index.rs:187-190)."""
+    ix, dim = _index()
+    ix.upload(0)
+    q = random_queries(62, 9, dim, 3, 40)
+    gs, gi, gn = ix.batch_search(*q, 10, 0, 0.9, False)
+    assert (gn == 0).all()
+    c = orc.batch_search(ix.desc, *q, 10, 0, 0.9, False)
+    assert (c[2] == 0).all()
+
+
+@pytest.mark.parametrize("hf", [-0.5, -2.0, 0.0])
+@pytest.mark.parametrize("scale", [1.0, -1.0])
+def test_any_heap_factor_matches_the_oracle(hf, scale):
+    """heap_factor * threshold falls as the threshold rises when the factor is negative (or the
+    scores are): the block filter must not use an older threshold then; the replay decides."""
+    dim = 300
+    off, comps, vals = random_dataset(63, 4000, dim, nnz_lo=8, nnz_hi=120, value_scale=1.0)
+    ix = _native.NativeIndex.build(2, dim, off, comps, vals * 1.0,
+                                   BuildConfig.defaults(n_postings=100, centroid_fraction=0.2, summary_energy=0.5,
+                                                        max_fraction=6.0)).upload(0)
+    q_off, qc, qv = random_queries(64, 40, dim, 3, 50)
+    qv = qv * scale   # negative query weights -> negative scores and thresholds
+    for srt in (False, True):
+        g = ix.batch_search(q_off, qc, qv, 10, 6, hf, srt)
+        c = orc.batch_search(ix.desc, q_off, qc, qv, 10, 6, hf, srt)[:3]
+        _same(g, c)
+
+
+def test_four_host_threads_on_one_index():
+    """sgpu_search / sgpu_batch_search are re-entrant on a shared index (the reference's search takes
+    &self; S: Sync, src/index_traits.rs:106-113): 4 threads hammer one index with different
+    batches, batch sizes and parameters; every answer equals the oracle's."""
+    ix, dim = _index(65, 8000, 500)
+    ix.upload(0)
+    jobs = []
+    for t in range(4):
+        q = random_queries(70 + t, 48 + 16 * t, dim, 3, 60)
+        k, cut, hf, srt = [(10, 4, 1.0, False), (7, 6, 0.8, True), (100, 5, 0.9, False), (1, 3, 0.7, True)][t]
+        exp = orc.batch_search(ix.desc, *q, k, cut, hf, srt)[:3]
+        jobs.append((q, (k, cut, hf, srt), exp))
+    errors = []
+
+    def worker(t):
+        q, (k, cut, hf, srt), exp = jobs[t]
+        try:
+            for it in range(25):
+                if it % 5 == 4:   # single-query calls in between
+                    i = it % (len(q[0]) - 1)
+                    s, ids = ix.search(q[1][q[0][i]:q[0][i + 1]], q[2][q[0][i]:q[0][i + 1]], k, cut, hf, srt)
+                    n = int(exp[2][i])
+                    assert np.array_equal(ids, exp[1][i, :n]) and np.array_equal(s.view(np.uint32), exp[0][i, :n].view(np.uint32))
+                else:
+                    _same(ix.batch_search(*q, k, cut, hf, srt), exp)
+        except Exception as e:   # noqa: BLE001 - reported to the main thread
+            errors.append((t, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
+def test_replicas_shard_a_batch_in_process():
+    """sgpu_index_upload_many: replica 0 from the host, the others GPU to GPU; sgpu_batch_search cuts
+    the batch into contiguous shards, one host thread per replica, rows in input order. (On a 1-GPU
+    box the replicas share device 0: same code path, same peer-copy call.)"""
+    ix, dim = _index(66, 6000, 450)
+    ndev = _native.device_count()
+    devs = list(range(ndev)) if ndev >= 2 else [0, 0, 0]
+    ix.upload_many(devs)
+    assert ix.replicas == len(devs)
+    q = random_queries(67, 101, dim, 3, 50)   # 101: uneven shards
+    for (k, cut, hf, srt) in [(10, 4, 1.0, False), (20, 8, 0.8, True)]:
+        _same(ix.batch_search(*q, k, cut, hf, srt), orc.batch_search(ix.desc, *q, k, cut, hf, srt)[:3])
+    # device-resident batches on a chosen replica
+    b = _native.DeviceBatch(ix, *q, 10, replica=len(devs) - 1)
+    b.run(10, 4, 1.0, False)
+    _same(b.fetch(10), orc.batch_search(ix.desc, *q, 10, 4, 1.0, False)[:3])
+    ix.upload(0)   # back to one replica
+    assert ix.replicas == 1
+    _same(ix.batch_search(*q, 10, 4, 1.0, False), orc.batch_search(ix.desc, *q, 10, 4, 1.0, False)[:3])
+
+
+def test_knn_graph_survives_save_and_load(tmp_path):
+    """The reference serialises the kNN graph inside the index file (InvertedIndexBase{.., knn}):
+    build(nknn) -> save -> load keeps n_knn refinement working."""
+    ix, dim = _index(68, 3000, 300)
+    ix.upload(0)
+    ix.build_knn(5)
+    q = random_queries(69, 30, dim, 3, 40)
+    before = ix.batch_search(*q, 10, 3, 0.9, False, n_knn=3)
+    plain = ix.batch_search(*q, 10, 3, 0.9, False)
+    assert not np.array_equal(before[1], plain[1])            # the refinement does change results here
+    p = str(tmp_path / "with_knn.idx")
+    ix.save(p)
+    ix2 = _native.NativeIndex.load(p).upload(0)
+    nb, kd = ix2.get_knn()
+    assert kd == 5 and np.array_equal(nb, ix.get_knn()[0])
+    _same(ix2.batch_search(*q, 10, 3, 0.9, False, n_knn=3), before)
+
+
+@pytest.mark.parametrize("cls,dim", [(seismic_amd.SeismicIndexRaw, 500), (seismic_amd.SeismicIndexRawLV, 90_000)])
+def test_raw_classes_over_the_inner_format(cls, dim, tmp_path):
+    """SeismicIndexRaw / SeismicIndexRawLV (reference src/pylib/mod.rs:663-1151): build from
+    documents.bin, search with integer components, batch_search from queries.bin."""
+    off, comps, vals = random_dataset(71, 3000, dim, nnz_lo=8, nnz_hi=100)
+    dp, qp = str(tmp_path / "documents.bin"), str(tmp_path / "queries.bin")
+    seismic_amd.write_inner_format(dp, off, comps, vals)
+    q = random_queries(72, 25, dim, 3, 40)
+    seismic_amd.write_inner_format(qp, *q)
+    ix = cls.build(dp, n_postings=60 if dim == 500 else 2, centroid_fraction=0.2, summary_energy=0.5, max_fraction=6.0)
+    assert ix.len == 3000 and ix.nnz == int(off[-1])
+    desc = ix._ix.desc
+    exp = orc.batch_search(desc, *q, 10, 5, 0.8, True)
+    got = ix.batch_search(qp, 10, 5, 0.8, 0, True)
+    for i, row in enumerate(got):
+        n = int(exp[2][i])
+        assert [d for _, d in row] == exp[1][i, :n].tolist()
+        assert [np.float32(s) for s, _ in row] == exp[0][i, :n].tolist()
+    one = ix.search(q[1][q[0][3]:q[0][4]].astype(np.int32), q[2][q[0][3]:q[0][4]], 10, 5, 0.8, 0, True)
+    assert one == got[3]
+    # save / load round trip of the raw index
+    ip = str(tmp_path / "raw.idx")
+    ix.save(ip)
+    assert cls.load(ip).batch_search(qp, 10, 5, 0.8, 0, True) == got
+    with pytest.raises(IOError):
+        cls.load(str(tmp_path / "missing.idx"))

@@ -1,0 +1,109 @@
+"""Full-size GPU parity (BASELINE configs 3 and 5) and the reference-facing tolerance of the
+document-score accumulation order. Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import orc
+from seismic_amd import _native
+from seismic_amd._abi import BuildConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(gpu, cpu):
+    gs, gi, gn = gpu
+    cs, ci, cn = cpu
+    assert np.array_equal(gn, cn)
+    assert np.array_equal(gi, ci)
+    assert np.array_equal(gs.view(np.uint32), cs.view(np.uint32))
+
+
+def test_c3_msmarco_shape_full_size_bit_exact():
+    """BASELINE config 3: 8.8M docs x 30K vocab, best_configs parameters, k=10 - the configuration the
+    metric is quoted on. All 1000 queries bit-identical to the CPU oracle, both traversal modes of
+    the first list, plus the batch-size independence of the answer (a 10 000-query batch holds the
+    same rows)."""
+    dim, n_docs, nq = 30_000, 8_800_000, 1000
+    docs = _native.synth(n_docs, dim, 42, 0)
+    ix = _native.NativeIndex.build(2, dim, *docs, BuildConfig.defaults(n_postings=2000, centroid_fraction=0.2,
+                                                                        summary_energy=0.5, max_fraction=6.0))
+    ix.upload(0)
+    big = _native.synth(10 * nq, dim, 43, 1, docs)
+    del docs
+    off = big[0][:nq + 1].copy()
+    q = (off, big[1][:int(off[nq])], big[2][:int(off[nq])])
+    for srt in (False, True):
+        g = ix.batch_search(*q, 10, 4, 1.0, srt)
+        c = orc.batch_search(ix.desc, *q, 10, 4, 1.0, srt)[:3]
+        _same(g, c)
+        assert (g[2] == 10).all()
+    gb = ix.batch_search(*big, 10, 4, 1.0, False)
+    g = ix.batch_search(*q, 10, 4, 1.0, False)
+    _same(tuple(a[:nq] for a in gb), g)
+    assert (np.diff(gb[0], axis=1) <= 0).all()                        # best first, every row
+    rows = np.sort(gb[1], axis=1)
+    assert (np.diff(rows.astype(np.int64), axis=1) > 0).all()          # no document twice in a row
+
+
+def test_c5_large_vocabulary_1m_docs_k100_heap_factor_sweep():
+    """BASELINE config 5 at 1M docs x 200K vocabulary (u32 components, SeismicIndexLV path), k=100,
+    query_cut=10, heap_factor in {0.7, 0.8, 0.9, 1.0}: bit-identical to the oracle."""
+    dim, n_docs, nq = 200_000, 1_000_000, 300
+    docs = _native.synth(n_docs, dim, 42, 0)
+    ix = _native.NativeIndex.build(4, dim, *docs, BuildConfig.defaults(n_postings=2000, centroid_fraction=0.1,
+                                                                        summary_energy=0.4, max_fraction=4.0,
+                                                                        min_cluster_size=10))
+    ix.upload(0)
+    q = _native.synth(nq, dim, 43, 1, docs)
+    del docs
+    for hf in (0.7, 0.8, 0.9, 1.0):
+        g = ix.batch_search(*q, 100, 10, hf, False)
+        c = orc.batch_search(ix.desc, *q, 100, 10, hf, False)[:3]
+        _same(g, c)
+    g = ix.batch_search(*q, 100, 10, 0.9, True)
+    _same(g, orc.batch_search(ix.desc, *q, 100, 10, 0.9, True)[:3])
+
+
+def test_accumulation_order_tolerance_at_full_size(capsys):
+    """The document-score accumulation order lives in vectorium (not in the reference tree); the
+    kernel's order (16 lane accumulators + butterfly) is bit-exact against the oracle's LANES16
+    restatement. This test measures the kernel against the oracle run with the PLAIN LEFT-TO-RIGHT
+    order (SURVEY.md 8c's restatement) at BASELINE config 2: scores of common documents within
+    1e-5 * max(1, |s|) (DESIGN.md's stated tolerance); the number of queries whose id list differs is
+    reported, and every difference must be a near-tie at the k-th place."""
+    dim, n_docs, nq, k = 30_000, 1_000_000, 1000, 10
+    docs = _native.synth(n_docs, dim, 42, 0)
+    ix = _native.NativeIndex.build(2, dim, *docs, BuildConfig.defaults(n_postings=2000, centroid_fraction=0.2,
+                                                                        summary_energy=0.5, max_fraction=6.0))
+    ix.upload(0)
+    q = _native.synth(nq, dim, 43, 1, docs)
+    del docs
+    gs, gi, gn = ix.batch_search(*q, k, 4, 1.0, False)
+    ss, si, sn, _, _, _ = orc.batch_search(ix.desc, *q, k, 4, 1.0, False, order=orc.ORDER_SEQ)
+    assert np.array_equal(gn, sn)
+    differ, unexplained, max_rel = 0, 0, 0.0
+    for i in range(nq):
+        n = int(gn[i])
+        g = dict(zip(gi[i, :n].tolist(), gs[i, :n].tolist()))
+        s = dict(zip(si[i, :n].tolist(), ss[i, :n].tolist()))
+        for d_ in g.keys() & s.keys():
+            tol = 1e-5 * max(1.0, abs(s[d_]))
+            assert abs(g[d_] - s[d_]) <= tol, (i, d_, g[d_], s[d_])
+            max_rel = max(max_rel, abs(g[d_] - s[d_]) / max(1.0, abs(s[d_])))
+        if gi[i, :n].tolist() != si[i, :n].tolist():
+            differ += 1
+            kth_g, kth_s = float(gs[i, n - 1]), float(ss[i, n - 1])
+            tol = 1e-5 * max(1.0, abs(kth_s))
+            ok = all(abs(g[d_] - kth_s) <= tol for d_ in g.keys() - s.keys()) and \
+                all(abs(s[d_] - kth_g) <= tol for d_ in s.keys() - g.keys())
+            # same set in another order: only near-equal scores may swap
+            if ok and g.keys() == s.keys():
+                order_g = gi[i, :n].tolist()
+                order_s = si[i, :n].tolist()
+                ok = all(abs(g[a] - g[b]) <= tol for a, b in zip(order_g, order_s) if a != b)
+            unexplained += 0 if ok else 1
+    with capsys.disabled():
+        print("\n[order tolerance] %d queries: %d id lists differ from the left-to-right order, %d not "
+              "explained by a near-tie; max |ds|/max(1,|s|) = %.2e" % (nq, differ, unexplained, max_rel))
+    assert unexplained == 0
+    assert differ <= nq // 100
