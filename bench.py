@@ -75,6 +75,8 @@ def parse_args():
     ap.add_argument("--no-recall", action="store_true", help="skip recall@k vs exact")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end sgpu_batch_search measurement")
+    ap.add_argument("--no-accounting", action="store_true",
+                    help="skip the counted passes (PMC profiling runs: only the timed kernel variant is dispatched)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
     ap.add_argument("--index-cache", default=os.environ.get("SGPU_INDEX_CACHE", ""))
     ap.add_argument("--traffic-bytes", type=float, default=None,
@@ -242,6 +244,10 @@ def main():
     for bi in timed_ids:
         b = batches[bi]
         gsc, gid, gn = b.fetch(args.k)
+        if args.no_accounting:
+            results[bi] = (gsc, gid, gn)
+            algo.append(0)
+            continue
         b.run_counted(args.k, args.query_cut, args.heap_factor, srt)
         csc, cid, cn = b.fetch(args.k)
         counted_identical &= bool(np.array_equal(cn, gn) and np.array_equal(cid, gid)

@@ -39,6 +39,8 @@ struct Lane {
   hipStream_t stream = nullptr;
   uint32_t* queue = nullptr;       // the launch's work counter (queries are pulled from it)
   sgpu_batch* scratch = nullptr;   // pool lanes: the recycled device batch (no allocation per call)
+  uint32_t* bitmaps = nullptr;     // visited bitmaps of the counted pass, one per resident workgroup
+  uint32_t bitmaps_slots = 0;
   std::vector<hipEvent_t> ev0, ev1;   // timing of enqueued launches
   int ev_pending = 0;
   double sum_ms = 0;
@@ -67,9 +69,7 @@ struct DeviceIndex {
   Lane main;
   Lane pool[kPool];
   std::unordered_map<uint64_t, int> occupancy;   // kernel variant + LDS size -> workgroups per CU
-  uint32_t* bitmaps = nullptr;                   // visited bitmaps of the counted pass (main lane only)
-  uint32_t bitmaps_slots = 0;
-  std::mutex mu;        // main lane, occupancy cache, bitmaps
+  std::mutex mu;        // main lane, occupancy cache
   std::mutex pool_mu;   // pool lane hand-out
   std::condition_variable pool_cv;
 };
@@ -92,6 +92,7 @@ static void lane_free(Lane* l) {
   if (l->stream) (void)hipStreamSynchronize(l->stream);
   if (l->scratch) batch_free(l->scratch);
   if (l->queue) (void)hipFree(l->queue);
+  if (l->bitmaps) (void)hipFree(l->bitmaps);
   for (hipEvent_t e : l->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : l->ev1) (void)hipEventDestroy(e);
   if (l->stream) (void)hipStreamDestroy(l->stream);
@@ -139,7 +140,6 @@ void device_index_free(DeviceIndex* d) {
   lane_free(&d->main);
   for (Lane& l : d->pool) lane_free(&l);
   for (const Alloc& a : d->allocs) (void)hipFree(a.p);
-  if (d->bitmaps) (void)hipFree(d->bitmaps);
   delete d;
 }
 
@@ -750,25 +750,24 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   uint32_t grid = d->n_cu * (uint32_t)per_cu;
   grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
   a->grid = grid;
-  // visited bitmaps: one per resident workgroup (counted pass; main lane only)
+  // visited bitmaps: one per resident workgroup (counted pass)
   a->bitmaps = nullptr;
   if (a->p.use_bitmap) {
-    if (lane != &d->main) return fail(SGPU_EINVAL, "the counted pass runs on the index's main lane only");
-    if (d->bitmaps_slots < grid) {
-      if (d->bitmaps) {
+    if (lane->bitmaps_slots < grid) {
+      if (lane->bitmaps) {
         HIP_TRY(hipStreamSynchronize(lane->stream));
-        (void)hipFree(d->bitmaps);
+        (void)hipFree(lane->bitmaps);
       }
-      d->bitmaps = nullptr;
-      d->bitmaps_slots = 0;
+      lane->bitmaps = nullptr;
+      lane->bitmaps_slots = 0;
       const uint32_t slots = std::max<uint32_t>(grid, d->n_cu * (uint32_t)per_cu);
       const size_t bytes = (size_t)slots * std::max<uint32_t>(d->view.n_bitmap_words, 1) * 4;
-      if (hipMalloc((void**)&d->bitmaps, bytes) != hipSuccess)
+      if (hipMalloc((void**)&lane->bitmaps, bytes) != hipSuccess)
         return fail(SGPU_ENOMEM, "hipMalloc of %zu bytes of visited bitmaps failed", bytes);
-      HIP_TRY(hipMemsetAsync(d->bitmaps, 0, bytes, lane->stream));
-      d->bitmaps_slots = slots;
+      HIP_TRY(hipMemsetAsync(lane->bitmaps, 0, bytes, lane->stream));
+      lane->bitmaps_slots = slots;
     }
-    a->bitmaps = d->bitmaps;
+    a->bitmaps = lane->bitmaps;
   }
   a->queue = lane->queue;
   return SGPU_OK;
