@@ -65,6 +65,7 @@ struct DeviceIndex {
   uint32_t max_lds = 0;
   std::vector<uint32_t> list_nb, list_np;   // blocks / postings per posting list (host copy)
   uint32_t max_nb = 0;
+  bool fwd_block_major = false;   // forward store holds a copy of every posting's record, block by block
   static constexpr int kMainEvents = 64, kPool = 4;
   Lane main;
   Lane pool[kPool];
@@ -151,6 +152,26 @@ int device_count() {
   return n;
 }
 
+// Block-major forward store: the record of every posting is copied next to the records of its
+// block-mates, so that a block's documents are ONE contiguous run of HBM. One 16-lane group per
+// posting, 16 bytes per lane and step (the document-major store is the source).
+__global__ __launch_bounds__(256) void replicate_records_kernel(uint8_t* fwd, const uint64_t* __restrict__ doc_ref,
+                                                                const uint32_t* __restrict__ post_doc,
+                                                                const uint64_t* __restrict__ post_ref, uint64_t n_postings,
+                                                                uint32_t unit16_per_elem8) {
+  const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const uint32_t sub = threadIdx.x & 15;
+  const uint64_t n_groups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+  for (uint64_t p = g; p < n_postings; p += n_groups) {
+    const uint64_t dst = post_ref[p], src = doc_ref[post_doc[p]];
+    const uint32_t len = (uint32_t)(dst & 0xffffu);
+    const uint32_t n16 = ((len + 7u) >> 3) * unit16_per_elem8;   // 16-byte units of the record
+    const uint4* s4 = (const uint4*)(fwd + (src >> 16) * 16ull);
+    uint4* d4 = (uint4*)(fwd + (dst >> 16) * 16ull);
+    for (uint32_t i = sub; i < n16; i += 16) d4[i] = s4[i];
+  }
+}
+
 // Packs the canonical arrays into the HBM layout and copies them to `device`.
 sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** out) {
   int n_dev = 0;
@@ -217,17 +238,64 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
         for (uint64_t e = len; e < npad; ++e) ((uint32_t*)rec)[e] = (uint32_t)h.dim;
       }
     }
-    if ((st = dev_copy(d, fwd.data(), fwd.size(), &d->view.fwd)) != SGPU_OK) return bail(st);
+    // ---- postings: (record offset / 16) << 16 | len, the reference's PackedPostingBlock
+    // (src/posting_list.rs:32-60). Forward store layout:
+    //   block-major (default when it fits): after the document-major records, every posting gets its
+    //     own copy of its document's record, laid out block by block (a block starts on a 128-byte
+    //     line, its records follow each other). A block's documents are then one contiguous run of
+    //     HBM: whole lines are useful and consecutive lines share DRAM pages, where document-major
+    //     records are ~4 scattered lines each with the first and last one half used. It costs
+    //     n_postings / n_docs (5-6x on MS MARCO shapes: 23 GB) of the 288 GB.
+    //   document-major: one record per document, postings point into it (large indexes).
+    const uint64_t doc_units = rec_off16[h.n_docs];
+    std::vector<uint64_t> pref(h.n_postings());
+    uint64_t blk_units = 0;
+    {
+      const uint64_t nb = h.n_blocks();
+      std::vector<uint64_t> bsize(nb + 1, 0);
+#pragma omp parallel for schedule(static)
+      for (int64_t b = 0; b < (int64_t)nb; ++b) {
+        uint64_t u = 0;
+        for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
+          const uint32_t doc = h.post_doc[p];
+          const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
+          u += ((len + 7) & ~7ull) * (cw + 2) / 16;
+        }
+        bsize[(size_t)b + 1] = (u + 7) & ~7ull;   // blocks start on 128-byte lines
+      }
+      for (uint64_t b = 0; b < nb; ++b) bsize[b + 1] += bsize[b];
+      blk_units = bsize[nb];
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      const char* env_layout = std::getenv("SGPU_FWD_LAYOUT");   // "block" | "doc"; default: block when it fits
+      const uint64_t need = (doc_units + blk_units) * 16 + h.n_postings() * 24 + h.n_entries() * 8;
+      bool block_major = blk_units > 0 && (doc_units + 8 + blk_units) < (1ull << 48) &&
+                         need < (uint64_t)(0.6 * (double)free_b) && blk_units * 16 <= (96ull << 30);
+      if (env_layout && std::strcmp(env_layout, "doc") == 0) block_major = false;
+      if (env_layout && std::strcmp(env_layout, "block") == 0 && blk_units > 0) block_major = true;
+      const uint64_t blk_base = (doc_units + 7) & ~7ull;
+      d->fwd_block_major = block_major;
+#pragma omp parallel for schedule(static)
+      for (int64_t b = 0; b < (int64_t)nb; ++b) {
+        uint64_t cur = blk_base + bsize[(size_t)b];
+        for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
+          const uint32_t doc = h.post_doc[p];
+          const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
+          pref[p] = ((block_major ? cur : rec_off16[doc]) << 16) | len;
+          cur += ((len + 7) & ~7ull) * (cw + 2) / 16;
+        }
+      }
+      const uint64_t total_units = block_major ? blk_base + blk_units : doc_units;
+      void* fp = nullptr;
+      const size_t fbytes = std::max<uint64_t>(total_units * 16, 16);
+      if (hipMalloc(&fp, fbytes) != hipSuccess) return bail(fail(SGPU_ENOMEM, "hipMalloc of %zu bytes failed", fbytes));
+      d->allocs.push_back(Alloc{fp, fbytes, (size_t)((const char*)&d->view.fwd - (const char*)d)});
+      d->bytes += fbytes;
+      d->view.fwd = (const uint8_t*)fp;
+      HIP_TRY(hipMemcpy(fp, fwd.data(), fwd.size(), hipMemcpyHostToDevice));
+    }
     fwd.clear();
     fwd.shrink_to_fit();
-    // ---- postings
-    std::vector<uint64_t> pref(h.n_postings());
-#pragma omp parallel for schedule(static)
-    for (int64_t p = 0; p < (int64_t)pref.size(); ++p) {
-      const uint32_t doc = h.post_doc[(size_t)p];
-      const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
-      pref[(size_t)p] = (rec_off16[doc] << 16) | len;
-    }
     if ((st = dev_copy(d, pref.data(), pref.size(), &d->view.post_ref)) != SGPU_OK) return bail(st);
     {
       std::vector<uint64_t> dref(h.n_docs);
@@ -238,6 +306,13 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     pref.clear();
     pref.shrink_to_fit();
     if ((st = dev_copy(d, h.post_doc.data(), h.post_doc.size(), &d->view.post_doc)) != SGPU_OK) return bail(st);
+    if (d->fwd_block_major && h.n_postings()) {
+      hipLaunchKernelGGL(replicate_records_kernel, dim3(d->n_cu * 8), dim3(256), 0, d->main.stream,
+                         (uint8_t*)d->view.fwd, d->view.doc_ref, d->view.post_doc, d->view.post_ref,
+                         (uint64_t)h.n_postings(), (uint32_t)(8 * (cw + 2) / 16));
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(d->main.stream));
+    }
     auto narrow = [](const std::vector<uint64_t>& v) {
       std::vector<uint32_t> o(v.size());
       for (size_t i = 0; i < v.size(); ++i) o[i] = (uint32_t)v[i];
@@ -339,6 +414,7 @@ sgpu_status device_index_clone(const DeviceIndex* src, int device, DeviceIndex**
   d->list_nb = src->list_nb;
   d->list_np = src->list_np;
   d->max_nb = src->max_nb;
+  d->fwd_block_major = src->fwd_block_major;
   auto bail = [&](sgpu_status s) {
     device_index_free(d);
     return s;

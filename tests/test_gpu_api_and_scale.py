@@ -67,6 +67,8 @@ def test_golden_synth_small_on_gpu():
     dict(SGPU_BLOCK="1024", SGPU_STAGE_BYTES="8192"),                                        # many staging windows
     dict(SGPU_NO_LPT="1", SGPU_ITEMS_INIT="1024"),
     dict(SGPU_VISITED_BITMAP="1"),
+    dict(SGPU_FWD_LAYOUT="doc"),                                                              # one record per document
+    dict(SGPU_FWD_LAYOUT="doc", SGPU_REC_LINE="16"),
 ])
 def test_kernel_paths_under_forced_small_buffers(env, monkeypatch):
     for k_, v_ in env.items():
