@@ -16,7 +16,18 @@
 
 namespace sgpu {
 
-hipError_t occupancy_search(const LaunchArgs& a, int* blocks_per_cu);   // search_kernel.hip
+// one translation unit per kernel family (sk_*.hip): occupancy query when `occupancy` is given, else launch
+hipError_t run_u16_dense(const LaunchArgs& a, int* occupancy);
+hipError_t run_u16_packed(const LaunchArgs& a, int* occupancy);
+hipError_t run_u32_split(const LaunchArgs& a, int* occupancy);
+hipError_t run_u32_packed(const LaunchArgs& a, int* occupancy);
+
+static hipError_t run_any(const LaunchArgs& a, int* occ) {
+  if (a.comp_width == 2) return a.lookup == LK_DENSE ? run_u16_dense(a, occ) : run_u16_packed(a, occ);
+  return a.lookup == LK_SPLIT ? run_u32_split(a, occ) : run_u32_packed(a, occ);
+}
+hipError_t occupancy_search(const LaunchArgs& a, int* blocks_per_cu) { return run_any(a, blocks_per_cu); }
+hipError_t launch_search(const LaunchArgs& a) { return run_any(a, nullptr); }
 
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \
@@ -452,6 +463,7 @@ struct sgpu_batch_plan {   // per (batch, query_cut): LDS need and processing or
   uint32_t query_cut = 0;
   uint32_t dots_cap = 1;    // max over queries of the blocks of the lists it walks
   uint32_t max_nb = 0;      // largest single list walked first (sort buffer sizing)
+  uint32_t max_list_nb = 1; // largest single list walked at all (smallest possible dots area)
   std::vector<uint32_t> order;   // queries, longest expected first
 };
 
@@ -628,8 +640,8 @@ static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, c
     sgpu_batch_plan pl;
     pl.query_cut = query_cut;
     std::vector<std::pair<uint64_t, uint32_t>> cost(b->nq);
-    uint32_t max_nb = 0, dots_cap = 1;
-#pragma omp parallel if (b->nq >= 2048) reduction(max : max_nb, dots_cap)
+    uint32_t max_nb = 0, dots_cap = 1, max_list_nb = 1;
+#pragma omp parallel if (b->nq >= 2048) reduction(max : max_nb, dots_cap, max_list_nb)
     {
       std::vector<std::pair<int32_t, uint32_t>> kv;
 #pragma omp for schedule(static)
@@ -647,6 +659,7 @@ static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, c
         for (size_t i = 0; i < nl; ++i) {
           nb += d->list_nb[kv[i].second];
           np += d->list_np[kv[i].second];
+          max_list_nb = std::max(max_list_nb, d->list_nb[kv[i].second]);
         }
         if (nl) max_nb = std::max(max_nb, d->list_nb[kv[0].second]);
         dots_cap = std::max(dots_cap, nb);
@@ -655,6 +668,7 @@ static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, c
     }
     pl.max_nb = max_nb;
     pl.dots_cap = dots_cap;
+    pl.max_list_nb = max_list_nb;
     std::stable_sort(cost.begin(), cost.end(),
                      [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) { return a.first > c.first; });
     pl.order.resize(b->nq);
@@ -683,7 +697,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   // list and the result is empty (src/inverted_index.rs:187-190); the LDS tables keep one slot.
   const uint32_t cut = mode == MODE_DOTS ? 1u : std::min<uint32_t>(sp.query_cut, qn);
   const uint32_t qc = std::max<uint32_t>(1, cut);
-  const uint32_t words = (d->view.dim + 31) / 32;
+  const uint32_t words = d->view.dim / 32 + 1;   // + the word of the padding sentinel `dim`
   uint32_t items_max = env_u32("SGPU_ITEMS_MAX", 1024);
   uint32_t dots_cap = 1, sort_nb = 0;
   const sgpu_batch_plan* pl = nullptr;
@@ -709,9 +723,27 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   L.rt_start = (uint32_t)o; o += up((uint64_t)qc * qn * 8);
   L.rt_mid = (uint32_t)o; o += up((uint64_t)qc * qn * 2);
   L.rt_pre = (uint32_t)o; o += up(2ull * qc * (qn + 1) * 4);   // two streams (block-id halves) per list
+  // Block dots: all of a query's lists at once when that fits next to everything else at 2 workgroups
+  // per CU; otherwise the kernel walks the lists in groups and the area shrinks, down to the largest
+  // single list (docs/Guidelines.md:44-70: query_cut 10 over lists of 3600 blocks is 144 KB at once).
+  if (pl && (uint64_t)dots_cap * 4 > 24u * 1024u) {
+    const uint64_t target = env_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);
+    const uint64_t rest = up((sp.first_sorted && searching) ? (uint64_t)sort_nb * 2 : 0) + up(2 * (NT / 64 + 1) * 4) +
+                          up((uint64_t)heap_variant(sp.k) * 64 * 8) +
+                          up(kStateWords * 4) +
+                          ((d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255) ? up((uint64_t)d->view.dim + 1)
+                                                                                             : up((uint64_t)words * 6)) +
+                          up(512 * 16 + NT * 12);
+    const uint64_t fit = target > o + rest ? (target - o - rest) / 4 : 0;
+    dots_cap = (uint32_t)std::max<uint64_t>(pl->max_list_nb, std::min<uint64_t>(dots_cap, std::max<uint64_t>(fit, 6144)));
+  }
+  dots_cap = std::min<uint32_t>(dots_cap, env_u32("SGPU_DOTS_CAP", 0xffffffffu));
+  if (pl) dots_cap = std::max(dots_cap, pl->max_list_nb);
+  L.dots_cap = dots_cap;
   L.dots = (uint32_t)o; o += up((uint64_t)dots_cap * 4);
   L.order = (uint32_t)o; o += up((sp.first_sorted && searching) ? (uint64_t)sort_nb * 2 : 0);
   L.part = (uint32_t)o; o += up(2 * (NT / 64 + 1) * 4);   // two scan scratch areas, used alternately
+  L.heap = (uint32_t)o; o += up((uint64_t)heap_variant(sp.k) * 64 * 8);   // the top-k between replays
   L.st = (uint32_t)o; o += up(kStateWords * 4);   // state words + candidate lists
   // [lookup table | union region (sort keys, item tables)]
   uint64_t sort_bytes = 0;
@@ -773,7 +805,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->p.first_sorted = sp.first_sorted != 0;
   a->p.mode = mode == MODE_COUNTED ? (uint32_t)MODE_SEARCH : mode;
   a->p.n_knn = mode == MODE_DOTS ? 0u : sp.n_knn;   // ignored when the index has no graph, as the reference does
-  a->p.use_bitmap = (mode == MODE_COUNTED || env_u32("SGPU_VISITED_BITMAP", 0)) ? 1u : 0u;
+  a->counted = (mode == MODE_COUNTED || env_u32("SGPU_VISITED_BITMAP", 0)) ? 1u : 0u;
   a->p.items_max = items_max;
   a->p.items_init = std::min<uint32_t>(items_max, env_u32("SGPU_ITEMS_INIT", 128));
   a->p.items_min = std::min<uint32_t>(a->p.items_init, env_u32("SGPU_ITEMS_MIN", 64));
@@ -810,7 +842,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   // occupancy of this kernel variant at this LDS size: queried once, then remembered
   int per_cu = 0;
   {
-    const uint64_t key = ((uint64_t)a->comp_width << 56) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
+    const uint64_t key = ((uint64_t)a->comp_width << 56) | ((uint64_t)a->counted << 55) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
                          ((uint64_t)heap_variant(a->p.k) << 28) | (uint64_t)(a->lds_bytes >> 4);
     auto it = d->occupancy.find(key);
     if (it == d->occupancy.end()) {
@@ -828,7 +860,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->grid = grid;
   // visited bitmaps: one per resident workgroup (counted pass)
   a->bitmaps = nullptr;
-  if (a->p.use_bitmap) {
+  if (a->counted) {
     if (lane->bitmaps_slots < grid) {
       if (lane->bitmaps) {
         HIP_TRY(hipStreamSynchronize(lane->stream));

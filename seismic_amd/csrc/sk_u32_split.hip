@@ -1,0 +1,6 @@
+// sk_u32_split.hip — the search kernel family for uint32_t components with the LK_SPLIT query lookup table.
+#include "search_kernel.inc"
+
+namespace sgpu {
+hipError_t run_u32_split(const LaunchArgs& a, int* occupancy) { return run_family<uint32_t, LK_SPLIT>(a, occupancy); }
+}  // namespace sgpu

@@ -235,3 +235,36 @@ def test_results_tsv_and_accuracy(tmp_path):
     assert res == {0: [7, 3], 1: [11]}
     gt = {0: [7, 9], 1: [11], 2: [5]}
     assert accuracy(res, gt) == pytest.approx(2 / 4)
+
+
+def test_inner_format_against_bytes_written_by_the_reference_converter(tmp_path):
+    """tests/golden/toy_inner/* was written by the reference's scripts/convert_json_to_inner_format.py
+    (tests/golden/make_fixtures.py runs it where /root/reference exists). The product must read those
+    bytes into exactly the CSR its own jsonl ingestion produces (same sorted token numbering, unknown
+    query tokens dropped), and write the same bytes back."""
+    import json
+    gold = os.path.join(GOLD, "toy_inner")
+    off, comps, vals = seismic_amd.read_inner_format(os.path.join(gold, "documents.bin"))
+    ids, vecs, _ = seismic_amd.index.read_jsonl(os.path.join(GOLD, "toy", "documents.jsonl"))
+    tm = seismic_amd.index._token_map(vecs)
+    assert tm == json.load(open(os.path.join(gold, "token_to_id_mapping.json")))
+    o2, c2, v2 = seismic_amd.index._to_csr(vecs, tm)
+    assert np.array_equal(off, o2) and np.array_equal(comps, c2) and np.array_equal(vals.view(np.uint32), v2.view(np.uint32))
+    assert len(off) - 1 == 20
+    for d in range(20):   # components ascending inside every vector, as the reference's reader requires
+        assert (np.diff(comps[off[d]:off[d + 1]].astype(np.int64)) > 0).all()
+    qo, qc, qv = seismic_amd.read_inner_format(os.path.join(gold, "queries.bin"))
+    _, qvecs, _ = seismic_amd.index.read_jsonl(os.path.join(GOLD, "toy", "queries.jsonl"))
+    assert len(qo) - 1 == len(qvecs) == 5
+    for i, qd in enumerate(qvecs):
+        c, v = _resolve(list(qd.keys()), list(qd.values()), tm)
+        assert np.array_equal(c, qc[qo[i]:qo[i + 1]]) and np.array_equal(v.view(np.uint32), qv[qo[i]:qo[i + 1]].view(np.uint32))
+    for name, arrs in (("documents.bin", (off, comps, vals)), ("queries.bin", (qo, qc, qv))):
+        p = str(tmp_path / name)
+        seismic_amd.write_inner_format(p, *arrs)
+        assert open(p, "rb").read() == open(os.path.join(gold, name), "rb").read()
+    with pytest.raises(IOError):
+        seismic_amd.read_inner_format(str(tmp_path / "missing.bin"))
+    open(str(tmp_path / "trunc.bin"), "wb").write(open(os.path.join(gold, "documents.bin"), "rb").read()[:1000])
+    with pytest.raises(IOError):
+        seismic_amd.read_inner_format(str(tmp_path / "trunc.bin"))

@@ -67,6 +67,7 @@ def test_golden_synth_small_on_gpu():
     dict(SGPU_BLOCK="1024", SGPU_STAGE_BYTES="8192"),                                        # many staging windows
     dict(SGPU_NO_LPT="1", SGPU_ITEMS_INIT="1024"),
     dict(SGPU_VISITED_BITMAP="1"),
+    dict(SGPU_DOTS_CAP="1"),                                                                  # one list per group
     dict(SGPU_FWD_LAYOUT="doc"),                                                              # one record per document
     dict(SGPU_FWD_LAYOUT="doc", SGPU_REC_LINE="16"),
 ])
@@ -143,3 +144,24 @@ def test_full_size_config_properties():
     # Python-default sorted=True on the same data
     b.run(10, 4, 1.0, True)
     _same(b.fetch(10), orc.batch_search(ix.desc, *q, 10, 4, 1.0, True)[:3])
+
+
+def test_guidelines_operating_point_lists_of_thousands_of_blocks():
+    """docs/Guidelines.md:44-70 (n_postings 3000, centroid_fraction 0.2, max_fraction 6, query_cut 10):
+    lists of up to 3600 blocks, ten of them per query - 144 KB of block dots if they had to sit in LDS
+    together. The kernel walks the lists in groups; the results are the oracle's."""
+    dim, n_docs = 1500, 300_000
+    docs = _native.synth(n_docs, dim, 42, 0)
+    ix = _native.NativeIndex.build(2, dim, *docs, BuildConfig.defaults(n_postings=3000, centroid_fraction=0.2,
+                                                                        summary_energy=0.4, max_fraction=6.0))
+    a = orc.desc_arrays(ix.desc)
+    nb = np.diff(a["list_block_start"].astype(np.int64))
+    assert nb.max() >= 3000, nb.max()
+    ix.upload(0)
+    q = _native.synth(120, dim, 43, 1, docs)
+    for srt in (True, False):
+        g = ix.batch_search(*q, 10, 10, 0.8, srt)
+        c = orc.batch_search(ix.desc, *q, 10, 10, 0.8, srt)[:3]
+        _same(g, c)
+    g = ix.batch_search(*q, 100, 10, 0.7, True)
+    _same(g, orc.batch_search(ix.desc, *q, 100, 10, 0.7, True)[:3])

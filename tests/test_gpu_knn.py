@@ -65,3 +65,22 @@ def test_knn_set_get_roundtrip_and_python_api(tmp_path):
     assert kd == 4 and np.array_equal(got, nb)
     with pytest.raises(_native.SeismicHipError):
         ix.set_knn(np.array([10 ** 6], np.uint32), 1)     # neighbour id out of range
+
+
+def test_knn_hand_computed_known_answer_on_gpu():
+    """tests/golden/kat_knn_hand.json (derivation: tests/test_oracle_kat.py::test_knn_hand_computed):
+    Knn::new through the GPU kernel and Knn::refine in the kernel give the hand-derived lists."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_knn_hand.json")))
+    off, comps, vals = orc.csr([(d["components"], d["values"]) for d in g["docs"]])
+    ix = _native.NativeIndex.build(2, g["dim"], off, comps, vals, BuildConfig.defaults(**g["build"])).upload(0)
+    ix.build_knn(g["nknn"])
+    nb, kd = ix.get_knn()
+    assert kd == g["nknn"] and nb.tolist() == g["expected_neighbours"]
+    q = g["refine_query"]
+    s0, i0 = ix.search(q["components"], q["values"], q["k"], q["query_cut"], q["heap_factor"], False)
+    assert i0.tolist() == g["expected_without_refine"]["ids"] and s0.tolist() == g["expected_without_refine"]["scores"]
+    s1, i1 = ix.search(q["components"], q["values"], q["k"], q["query_cut"], q["heap_factor"], False, n_knn=q["n_knn"])
+    assert i1.tolist() == g["expected_with_refine"]["ids"]
+    assert s1.tolist() == [4.0, 1.0, float(np.float32(0.1) * np.float32(4.0))]

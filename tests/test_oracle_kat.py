@@ -167,3 +167,76 @@ def test_f16_roundtrip_matches_numpy():
             assert got == (0x7bff if x > 0 else 0xfbff)
         else:
             assert got == int(ref.view(np.uint16)), (x, got)
+
+
+def test_knn_hand_computed():
+    """Knn::new / Knn::refine on five integer-valued documents, derived by hand.
+
+    Pairwise dot products: d0.d1=14 d0.d2=5 d0.d3=0 d0.d4=4 | d1.d2=10 d1.d3=0 d1.d4=3 | d2.d3=4 d2.d4=0 |
+    d3.d4=6; self products 17, 13, 26, 20, 10. Every posting list has at most three postings, hence one
+    block (max(1, floor(0.1 * len)) centroids). Knn::new searches each document with k = nknn + 1 = 3,
+    query_cut 10, heap_factor 0.7, lists in descending weight:
+      d0 (c0:4, c1:1): list 0 -> d0 17, d1 14, d4 4 (full, 3rd = 4); list 1 (summary dot >= 0.7*4): d2 5 > 4
+                       replaces d4 -> [d0, d1, d2] -> neighbours [1, 2]
+      d1 (c0:3, c1:2): list 0 -> d0 14, d1 13, d4 3; list 1: d2 10 replaces d4 -> [d0, d1, d2] -> [0, 2]
+      d2 (c1:5, c2:1): list 1 -> d2 26, d1 10, d0 5; list 2: d3 4 < 5 -> [d2, d1, d0] -> [1, 0]
+      d3 (c2:4, c3:2): list 2 -> d3 20, d2 4; list 3: d4 6 -> [d3, d4, d2] -> [4, 2]
+      d4 (c3:3, c0:1): list 3 -> d4 10, d3 6; list 0: d0 4 fills the heap, d1 3 < 4 -> [d4, d3, d0] -> [3, 0]
+    refine, query (c0: 0.1, c2: 1.0), k 3, query_cut 1 (list 2 only): d3 = 4.0, d2 = 1.0 (heap not full).
+      Snapshot [d3, d2]; d3's neighbours [4, 2]: d4 = 0.1 pushed (heap full, 3rd = 0.1), d2 visited;
+      d2's neighbours [1, 0]: d1 = 0.1*3 replaces d4, d0 = 0.1*4 replaces d1 -> ids [3, 2, 0]."""
+    g = json.load(open(os.path.join(GOLD, "kat_knn_hand.json")))
+    ix = _build([(d["components"], d["values"]) for d in g["docs"]], g["dim"], **g["build"])
+    a = orc.desc_arrays(ix.desc)
+    assert np.diff(a["list_block_start"].astype(np.int64)).tolist() == [1, 1, 1, 1]
+    nb = orc.knn_build(ix.desc, g["nknn"])
+    assert nb.tolist() == g["expected_neighbours"]
+    q = g["refine_query"]
+    s0, i0 = orc.search(ix.desc, q["components"], q["values"], q["k"], q["query_cut"], q["heap_factor"], False)
+    assert i0.tolist() == g["expected_without_refine"]["ids"] and s0.tolist() == g["expected_without_refine"]["scores"]
+    orc.knn_attach(nb, g["nknn"])
+    try:
+        s1, i1 = orc.search(ix.desc, q["components"], q["values"], q["k"], q["query_cut"], q["heap_factor"], False,
+                            n_knn=q["n_knn"])
+    finally:
+        orc.knn_attach(None, 0)
+    assert i1.tolist() == g["expected_with_refine"]["ids"]
+    w = np.float32(0.1)
+    assert s1.tolist() == [4.0, 1.0, float(w * np.float32(4.0))]
+
+
+def test_lossy_summary_distances_against_a_straight_line_loop():
+    """SURVEY 8(c)(iv): QuantizedSummary::distances (src/quantized_summary.rs:64-118) on LOSSY summaries
+    (real-valued data, u8 codes), checked against a scalar restatement written straight from the
+    source: for each query component in ascending order, for each entry of that component's row,
+    acc[block] += (f32(code) * quant[block] + min[block]) * qv - every operation rounded to f32."""
+    rng = np.random.default_rng(7)
+    dim, n_docs = 120, 2500
+    vecs = []
+    for _ in range(n_docs):
+        n = int(rng.integers(5, 40))
+        c = np.sort(rng.choice(dim, n, replace=False))
+        vecs.append((c, (rng.exponential(0.45, n) + 0.02).astype(np.float32)))
+    ix = _build(vecs, dim, n_postings=200, centroid_fraction=0.2, summary_energy=0.6, max_fraction=4.0)
+    a = orc.desc_arrays(ix.desc)
+    assert len(np.unique(a["sum_code"])) > 100          # the quantisation is genuinely lossy
+    lists = np.argsort(np.diff(a["list_block_start"].astype(np.int64)))[-5:]
+    f32 = np.float32
+    for t in range(6):
+        n = int(rng.integers(4, 50))
+        qc = np.sort(rng.choice(dim, n, replace=False)).astype(np.uint32)
+        qv = (rng.exponential(0.5, n) + 0.01).astype(np.float32)
+        for l in lists:
+            b0, b1 = int(a["list_block_start"][l]), int(a["list_block_start"][l + 1])
+            acc = [f32(0)] * (b1 - b0)
+            rows = {int(a["row_comp"][r]): r for r in range(int(a["list_row_start"][l]), int(a["list_row_start"][l + 1]))}
+            for c, v in zip(qc.tolist(), qv):
+                r = rows.get(c)
+                if r is None:
+                    continue
+                for e in range(int(a["row_ptr"][r]), int(a["row_ptr"][r + 1])):
+                    blk = int(a["sum_bid"][e])
+                    deq = f32(f32(f32(a["sum_code"][e]) * a["blk_quant"][b0 + blk]) + a["blk_min"][b0 + blk])
+                    acc[blk] = f32(acc[blk] + f32(deq * v))
+            got = orc.summary_distances(ix.desc, int(l), qc, qv)
+            assert np.array_equal(np.asarray(acc, np.float32).view(np.uint32), got.view(np.uint32)), (t, l)
