@@ -286,15 +286,20 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       if (env_layout && std::strcmp(env_layout, "block") == 0 && blk_units > 0) block_major = true;
       const uint64_t blk_base = (doc_units + 7) & ~7ull;
       d->fwd_block_major = block_major;
+      // Inside a block the records are grouped by the scoring loop's length class (<= 128 elements
+      // first, longer ones after; posting order within a class): the kernel scores a round class by
+      // class, so consecutive items of a class are then adjacent records.
 #pragma omp parallel for schedule(static)
       for (int64_t b = 0; b < (int64_t)nb; ++b) {
         uint64_t cur = blk_base + bsize[(size_t)b];
-        for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
-          const uint32_t doc = h.post_doc[p];
-          const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
-          pref[p] = ((block_major ? cur : rec_off16[doc]) << 16) | len;
-          cur += ((len + 7) & ~7ull) * (cw + 2) / 16;
-        }
+        for (int cls = 0; cls < 2; ++cls)
+          for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
+            const uint32_t doc = h.post_doc[p];
+            const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
+            if ((len > 128) != (cls == 1)) continue;
+            pref[p] = ((block_major ? cur : rec_off16[doc]) << 16) | len;
+            cur += ((len + 7) & ~7ull) * (cw + 2) / 16;
+          }
       }
       const uint64_t total_units = block_major ? blk_base + blk_units : doc_units;
       void* fp = nullptr;
