@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--max-fraction", type=float, default=6.0)
     ap.add_argument("--min-cluster-size", type=int, default=2)
     ap.add_argument("--comp-width", type=int, default=2, choices=[2, 4])
+    ap.add_argument("--value-type", default="f16", choices=["f16", "fixedu8"],
+                    help="document value storage (fixedu8: the forward index of the reference's DotVByte index)")
     ap.add_argument("--sample", type=int, default=1000,
                     help="queries of the first timed batch used for recall, the oracle identity check and cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -91,9 +93,10 @@ def parse_args():
 
 def workload_key(args, world, scaling):
     src = "docs=%d dim=%d" % (args.docs, args.dim) if not args.documents else "documents=%s" % os.path.basename(args.documents)
-    return "%s queries=%d k=%d query_cut=%d heap_factor=%s first_sorted=%d cw=%d np=%d cf=%g se=%g mf=%g" % (
+    key = "%s queries=%d k=%d query_cut=%d heap_factor=%s first_sorted=%d cw=%d np=%d cf=%g se=%g mf=%g" % (
         src, args.queries, args.k, args.query_cut, args.heap_factor, args.first_sorted, args.comp_width,
         args.n_postings, args.centroid_fraction, args.summary_energy, args.max_fraction)
+    return key if args.value_type == "f16" else key + " vt=" + args.value_type
 
 
 def main():
@@ -187,6 +190,8 @@ def main():
     if rank != 0:
         index = _native.NativeIndex.load(path)
         allq = _native.read_inner_format(qpath)
+    if args.value_type == "fixedu8":   # convert_dataset_into: same lists / blocks / summaries, u8 forward values
+        index = index.convert(1)
     t0 = time.time()
     index.upload(local_rank)
     t_up = time.time() - t0
@@ -252,7 +257,7 @@ def main():
         csc, cid, cn = b.fetch(args.k)
         counted_identical &= bool(np.array_equal(cn, gn) and np.array_equal(cid, gid)
                                   and np.array_equal(csc.view(np.uint32), gsc.view(np.uint32)))
-        ab, counters = b.algorithmic_bytes(args.k, args.comp_width)
+        ab, counters = b.algorithmic_bytes(args.k, args.comp_width, 2 if args.value_type == "f16" else 1)
         algo.append(ab)
         agg += counters[:, :8].sum(axis=0)
         results[bi] = (gsc, gid, gn)
@@ -304,7 +309,7 @@ def main():
                       "n_postings_kept": int(d.n_postings), "summary_entries": int(d.n_entries)},
             "query": {"k": args.k, "query_cut": args.query_cut, "heap_factor": args.heap_factor,
                       "first_sorted": srt},
-            "storage": "f16 document values, u%d components, u8-quantised block summaries" % (8 * args.comp_width),
+            "storage": "%s document values, u%d components, u8-quantised block summaries" % (args.value_type, 8 * args.comp_width),
             "parallelism": "index replicated, %s, no collective" % (
                 ("each batch of %d cut into %d contiguous shards" % (args.queries, world)) if scaling == "strong" and world > 1
                 else ("%d batch(es) of %d per step" % (world, args.queries))),

@@ -69,9 +69,19 @@ typedef enum sgpu_status {
  *     (the reference stores the same CSR with Elias-Fano offsets and a packed
  *      BitField of summary ids; the codecs carry no arithmetic.)
  * ---------------------------------------------------------------------- */
+/* Document value storage (the reference's value types, src/bin/build_inverted_index.rs:255-292):
+ *   SGPU_VAL_F16     half::f16, the default.
+ *   SGPU_VAL_FIXEDU8 unsigned 8-bit fixed point: value = code * val_scale. Replaces vectorium's
+ *                    FixedU8Q / the value half of DotVByteFixedU8Encoder ("8-bit fixed-point
+ *                    quantization (Q0.8)", docs/TomlInstructions.md:100). The codec is not in the
+ *                    reference tree: PARITY UNPINNED. Restated as: val_scale = the smallest power of
+ *                    two with 255 * val_scale >= the largest value (2^-8, i.e. Q0.8, for values
+ *                    below 1); code = min(255, round_half_away(v / val_scale)), negatives -> 0. */
+enum { SGPU_VAL_F16 = 0, SGPU_VAL_FIXEDU8 = 1 };
+
 typedef struct sgpu_index_desc {
   uint32_t comp_width;            /* 2 (SeismicIndex, u16) or 4 (SeismicIndexLV, u32) */
-  uint32_t reserved;
+  uint32_t value_type;            /* SGPU_VAL_F16 or SGPU_VAL_FIXEDU8: how fwd_vals stores document values */
   uint64_t n_docs;
   uint64_t dim;                   /* number of components == number of posting lists */
   uint64_t nnz;                   /* fwd_offsets[n_docs] */
@@ -81,7 +91,7 @@ typedef struct sgpu_index_desc {
   uint64_t n_entries;             /* row_ptr[n_rows] */
   const uint64_t* fwd_offsets;    /* n_docs + 1 */
   const void* fwd_comps;          /* nnz x comp_width bytes */
-  const uint16_t* fwd_vals;       /* nnz, binary16 bits */
+  const void* fwd_vals;           /* nnz binary16 bit patterns (F16) or nnz u8 codes (FIXEDU8) */
   const uint64_t* list_block_start; /* dim + 1 */
   const uint64_t* block_post_start; /* n_blocks + 1 */
   const uint32_t* post_doc;       /* n_postings */
@@ -92,6 +102,8 @@ typedef struct sgpu_index_desc {
   const uint64_t* row_ptr;        /* n_rows + 1 */
   const uint16_t* sum_bid;        /* n_entries */
   const uint8_t* sum_code;        /* n_entries */
+  float val_scale;                /* FIXEDU8: value = code * val_scale (a power of two); 0 for F16 */
+  uint32_t reserved;
 } sgpu_index_desc;
 
 /* Build-time configuration; mirrors Configuration (src/configurations.rs:15-129)
@@ -150,6 +162,11 @@ sgpu_status sgpu_index_build(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
                              const uint64_t* offsets, const void* comps,
                              const float* vals, const sgpu_build_config* cfg,
                              sgpu_index** out);
+/* Replaces: InvertedIndexBase::convert_dataset_into (call sites src/pylib/dotvbyte.rs:208-213,
+ * src/bin/build_inverted_index.rs:294-306): a new index with the same posting lists, blocks and
+ * summaries whose forward index stores the documents with another value type (F16 -> FIXEDU8 is what
+ * SeismicIndexDotVByte.build does after building the standard index). *out is independent of src. */
+sgpu_status sgpu_index_convert(const sgpu_index* src, uint32_t value_type, sgpu_index** out);
 /* View of the index's canonical host arrays; valid until sgpu_index_destroy. */
 sgpu_status sgpu_index_get_desc(const sgpu_index* idx, sgpu_index_desc* out);
 /* Replaces: IndexSerializer::save_index / load_index (src/pylib/mod.rs:186-221).

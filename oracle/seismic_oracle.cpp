@@ -142,6 +142,9 @@ struct OracleIndex {
   std::vector<uint64_t> fwd_offsets;
   std::vector<uint32_t> fwd_comps;  // kept as u32 internally; exported per comp_width
   std::vector<uint16_t> fwd_vals;
+  std::vector<uint8_t> fwd_codes;   // value_type FIXEDU8 (after orc_index_convert_fixedu8)
+  uint32_t value_type = SGPU_VAL_F16;
+  float val_scale = 0.0f;
   std::vector<uint64_t> list_block_start, block_post_start;
   std::vector<uint32_t> post_doc;
   std::vector<float> blk_min, blk_quant;
@@ -437,7 +440,9 @@ void fill_desc(OracleIndex* ix, sgpu_index_desc* out) {
     out->fwd_comps = ix->fwd_comps.data();
     out->row_comp = ix->row_comp.data();
   }
-  out->fwd_vals = ix->fwd_vals.data();
+  out->value_type = ix->value_type;
+  out->val_scale = ix->val_scale;
+  out->fwd_vals = ix->value_type == SGPU_VAL_FIXEDU8 ? (const void*)ix->fwd_codes.data() : (const void*)ix->fwd_vals.data();
   out->list_block_start = ix->list_block_start.data();
   out->block_post_start = ix->block_post_start.data();
   out->post_doc = ix->post_doc.data();
@@ -554,13 +559,22 @@ void summary_distances(const sgpu_index_desc& ix, uint32_t list, const uint32_t*
 // Both skip non-matching components; no FMA.
 enum { ORDER_LANES16 = 0, ORDER_SEQ = 1 };
 
+// Document value i of the forward index as f32. F16: exact widening. FIXEDU8 (vectorium's FixedU8Q /
+// DotVByteFixedU8Encoder, NOT in the reference tree - parity unpinned; docs/TomlInstructions.md:100
+// calls it "8-bit fixed-point quantization (Q0.8)"): [CHOICE] value = code * step with step a power
+// of two (2^-8 = Q0.8 when every value is below 1), so the product below is exact.
+inline float doc_val(const sgpu_index_desc& ix, uint64_t i) {
+  if (ix.value_type == SGPU_VAL_FIXEDU8) return (float)((const uint8_t*)ix.fwd_vals)[i] * ix.val_scale;
+  return f16_to_f32(((const uint16_t*)ix.fwd_vals)[i]);
+}
+
 inline float score_doc(const sgpu_index_desc& ix, uint32_t doc, const float* dense, int order) {
   const uint64_t s = ix.fwd_offsets[doc], e = ix.fwd_offsets[doc + 1];
   if (order == ORDER_SEQ) {
     float acc = 0.0f;
     for (uint64_t i = s; i < e; ++i) {
       float q = dense[comp_at(ix.fwd_comps, ix.comp_width, i)];
-      if (q != 0.0f) acc = acc + q * f16_to_f32(ix.fwd_vals[i]);
+      if (q != 0.0f) acc = acc + q * doc_val(ix, i);
     }
     return acc;
   }
@@ -570,7 +584,7 @@ inline float score_doc(const sgpu_index_desc& ix, uint32_t doc, const float* den
     float q = dense[comp_at(ix.fwd_comps, ix.comp_width, i)];
     if (q != 0.0f) {
       int lane = (int)(((i - s) >> 3) & 15);
-      t[lane] = t[lane] + q * f16_to_f32(ix.fwd_vals[i]);
+      t[lane] = t[lane] + q * doc_val(ix, i);
     }
   }
   for (int st = 8; st >= 1; st >>= 1) {
@@ -673,7 +687,7 @@ int search_one(const sgpu_index_desc& ix, QueryCtx& ctx, const uint32_t* qc, con
         if (ctx.visited_epoch[doc] == ctx.epoch) continue;
         const uint64_t o = ix.fwd_offsets[doc];
         __builtin_prefetch((const char*)ix.fwd_comps + o * cw);
-        __builtin_prefetch((const char*)ix.fwd_vals + o * 2);
+        __builtin_prefetch((const char*)ix.fwd_vals + o * (ix.value_type == SGPU_VAL_FIXEDU8 ? 1 : 2));
       }
       // pass 2 (src/posting_list.rs:206-214)
       for (uint64_t p = p0; p < p1; ++p) {
@@ -682,7 +696,7 @@ int search_one(const sgpu_index_desc& ix, QueryCtx& ctx, const uint32_t* qc, con
         ctx.visited_epoch[doc] = ctx.epoch;
         float d = score_doc(ix, doc, ctx.dense.data(), order);
         heap.push({d, doc});
-        bytes += 8 + (ix.fwd_offsets[doc + 1] - ix.fwd_offsets[doc]) * (cw + 2);
+        bytes += 8 + (ix.fwd_offsets[doc + 1] - ix.fwd_offsets[doc]) * (cw + (ix.value_type == SGPU_VAL_FIXEDU8 ? 1 : 2));
         if (st) st->docs_scored += 1;
       }
     }
@@ -739,6 +753,32 @@ orc_index* orc_index_build(uint32_t comp_width, uint64_t n_docs, uint64_t dim, c
 void orc_index_desc(orc_index* ix, sgpu_index_desc* out) { fill_desc((OracleIndex*)ix, out); }
 void orc_index_free(orc_index* ix) { delete (OracleIndex*)ix; }
 
+// InvertedIndexBase::convert_dataset_into::<PackedSparseDataset<DotVByteFixedU8Encoder>> (call sites
+// src/pylib/dotvbyte.rs:208-213, src/bin/build_inverted_index.rs:294-306): the standard f16 index is
+// built first, then the forward index is re-encoded; posting lists, blocks and summaries stay.
+// [CHOICE, parity unpinned] step = the smallest power of two with 255 * step >= the largest value
+// (2^-8 when all values are below 1: "Q0.8"); code = min(255, round(v / step)) with Rust's `round`
+// (half away from zero); the component stream of DotVByte is a lossless storage codec and carries
+// no arithmetic.
+orc_index* orc_index_convert_fixedu8(orc_index* src_) {
+  const OracleIndex* src = (const OracleIndex*)src_;
+  OracleIndex* ix = new OracleIndex(*src);
+  const uint64_t nnz = src->fwd_vals.size();
+  float vmax = 0.0f;
+  for (uint64_t i = 0; i < nnz; ++i) vmax = std::max(vmax, f16_to_f32(src->fwd_vals[i]));
+  float step = 1.0f / 256.0f;
+  while (255.0f * step < vmax) step *= 2.0f;
+  ix->value_type = SGPU_VAL_FIXEDU8;
+  ix->val_scale = step;
+  ix->fwd_codes.resize(nnz);
+  for (uint64_t i = 0; i < nnz; ++i) {
+    const float r = std::round(f16_to_f32(src->fwd_vals[i]) / step);
+    ix->fwd_codes[i] = r >= 255.0f ? 255 : (r > 0.0f ? (uint8_t)r : 0);
+  }
+  ix->fwd_vals.clear();
+  return (orc_index*)ix;
+}
+
 // kNN graph used by orc_search / orc_batch_search when params->n_knn > 0 (test infrastructure:
 // one process-wide attachment; pass NULL to detach).
 static KnnView g_knn;
@@ -764,7 +804,7 @@ uint64_t orc_knn_build(const sgpu_index_desc* ix, uint32_t nknn, uint32_t* out) 
     qv.clear();
     for (uint64_t i = ix->fwd_offsets[d]; i < ix->fwd_offsets[d + 1]; ++i) {
       qc.push_back(comp_at(ix->fwd_comps, ix->comp_width, i));
-      qv.push_back(f16_to_f32(ix->fwd_vals[i]));
+      qv.push_back(doc_val(*ix, i));
     }
     uint32_t n = 0;
     search_one(*ix, ctx, qc.data(), qv.data(), (uint32_t)qc.size(), k, 10, 0.7f, 0, ORDER_LANES16, sc.data(),

@@ -7,9 +7,9 @@ The compute path is libseismic_hip.so (hand-written HIP for gfx950 behind the C 
 include/seismic_hip.h). Importing this package does not load it; the first index operation does,
 and fails loudly if the library or a HIP device is missing (no CPU fallback).
 """
-from .index import (SeismicDataset, SeismicDatasetLV, SeismicIndex, SeismicIndexLV, SeismicIndexRaw,
+from .index import (SeismicDataset, SeismicDatasetLV, SeismicIndex, SeismicIndexDotVByte, SeismicIndexLV, SeismicIndexRaw,
                     SeismicIndexRawLV, get_seismic_string, read_inner_format, write_inner_format)
 
-__all__ = ["SeismicIndex", "SeismicIndexLV", "SeismicIndexRaw", "SeismicIndexRawLV", "SeismicDataset",
+__all__ = ["SeismicIndex", "SeismicIndexLV", "SeismicIndexDotVByte", "SeismicIndexRaw", "SeismicIndexRawLV", "SeismicDataset",
            "SeismicDatasetLV", "get_seismic_string", "read_inner_format", "write_inner_format"]
 __version__ = "0.1.0"

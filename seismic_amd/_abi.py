@@ -2,7 +2,8 @@
 import ctypes as C
 
 SGPU_OK, SGPU_EINVAL, SGPU_EDEVICE, SGPU_ENOMEM, SGPU_EIO, SGPU_ELIMIT = range(6)
-ABI_VERSION = 2
+ABI_VERSION = 3
+SGPU_VAL_F16, SGPU_VAL_FIXEDU8 = 0, 1
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)
@@ -14,7 +15,7 @@ f32p = C.POINTER(C.c_float)
 class IndexDesc(C.Structure):
     _fields_ = [
         ("comp_width", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("value_type", C.c_uint32),
         ("n_docs", C.c_uint64),
         ("dim", C.c_uint64),
         ("nnz", C.c_uint64),
@@ -24,7 +25,7 @@ class IndexDesc(C.Structure):
         ("n_entries", C.c_uint64),
         ("fwd_offsets", u64p),
         ("fwd_comps", C.c_void_p),
-        ("fwd_vals", u16p),
+        ("fwd_vals", C.c_void_p),
         ("list_block_start", u64p),
         ("block_post_start", u64p),
         ("post_doc", u32p),
@@ -35,6 +36,8 @@ class IndexDesc(C.Structure):
         ("row_ptr", u64p),
         ("sum_bid", u16p),
         ("sum_code", u8p),
+        ("val_scale", C.c_float),
+        ("reserved", C.c_uint32),
     ]
 
 

@@ -47,6 +47,7 @@ def lib():
         L.sgpu_index_get_desc.argtypes = [vp, C.POINTER(IndexDesc)]
         L.sgpu_index_save.argtypes = [vp, C.c_char_p]
         L.sgpu_index_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.sgpu_index_convert.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
         L.sgpu_index_upload.argtypes = [vp, C.c_int32]
         L.sgpu_index_upload_many.argtypes = [vp, vp, C.c_uint32]
         L.sgpu_index_replicas.argtypes = [vp]
@@ -143,6 +144,13 @@ class NativeIndex:
             check(lib().sgpu_index_get_desc(self.h, C.byref(d)))
             self._desc = d
         return self._desc
+
+    def convert(self, value_type):
+        """InvertedIndexBase::convert_dataset_into: a new index whose forward index stores the document
+        values as `value_type` (0 = f16, 1 = fixed-u8); lists, blocks and summaries are shared."""
+        h = C.c_void_p()
+        check(lib().sgpu_index_convert(self.h, int(value_type), C.byref(h)))
+        return NativeIndex(h.value)
 
     def upload(self, device=0):
         check(lib().sgpu_index_upload(self.h, int(device)))
@@ -276,12 +284,13 @@ class DeviceBatch:
         check(lib().sgpu_batch_fetch_stats(self.index.h, self.h, _p(st)))
         return st[: self.nq]
 
-    def algorithmic_bytes(self, k, comp_width):
-        """B_q of SURVEY.md 8(d), summed over the batch, from the kernel's own work counters."""
+    def algorithmic_bytes(self, k, comp_width, val_bytes=2):
+        """B_q of SURVEY.md 8(d), summed over the batch, from the kernel's own work counters
+        (val_bytes: 2 for f16 document values, 1 for fixed-u8)."""
         st = self.fetch_stats().astype(np.int64)
         nnz_q = np.diff(self.q_off.astype(np.int64))
         b = (nnz_q * (comp_width + 4) + 12 * k + 8 * st[:, 0] + 8 * st[:, 1] + 3 * st[:, 2]
-             + 4 * (st[:, 4] + st[:, 3]) + 8 * st[:, 5] + st[:, 6] * (comp_width + 2))
+             + 4 * (st[:, 4] + st[:, 3]) + 8 * st[:, 5] + st[:, 6] * (comp_width + val_bytes))
         return int(b.sum()), st
 
     def close(self):

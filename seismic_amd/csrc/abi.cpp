@@ -41,7 +41,7 @@ using namespace sgpu;
 extern "C" {
 
 const char* sgpu_last_error(void) { return last_error().c_str(); }
-uint32_t sgpu_abi_version(void) { return 2; }
+uint32_t sgpu_abi_version(void) { return 3; }
 
 sgpu_status sgpu_device_count(int32_t* n) {
   if (!n) return fail(SGPU_EINVAL, "null argument");
@@ -73,6 +73,19 @@ sgpu_status sgpu_index_build(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
   sgpu_index* ix = new (std::nothrow) sgpu_index();
   if (!ix) return fail(SGPU_ENOMEM, "out of memory");
   sgpu_status st = build_host_index(comp_width, n_docs, dim, offsets, comps, vals, *cfg, &ix->host);
+  if (st != SGPU_OK) {
+    delete ix;
+    return st;
+  }
+  *out = ix;
+  return SGPU_OK;
+}
+
+sgpu_status sgpu_index_convert(const sgpu_index* src, uint32_t value_type, sgpu_index** out) {
+  if (!src || !out) return fail(SGPU_EINVAL, "null argument");
+  sgpu_index* ix = new (std::nothrow) sgpu_index();
+  if (!ix) return fail(SGPU_ENOMEM, "out of memory");
+  sgpu_status st = host_index_convert(src->host, value_type, &ix->host);
   if (st != SGPU_OK) {
     delete ix;
     return st;

@@ -21,8 +21,11 @@ hipError_t run_u16_dense(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_packed(const LaunchArgs& a, int* occupancy);
 hipError_t run_u32_split(const LaunchArgs& a, int* occupancy);
 hipError_t run_u32_packed(const LaunchArgs& a, int* occupancy);
+hipError_t run_u16_dense_u8(const LaunchArgs& a, int* occupancy);
+hipError_t run_u16_packed_u8(const LaunchArgs& a, int* occupancy);
 
 static hipError_t run_any(const LaunchArgs& a, int* occ) {
+  if (a.value_type == SGPU_VAL_FIXEDU8) return a.lookup == LK_DENSE ? run_u16_dense_u8(a, occ) : run_u16_packed_u8(a, occ);
   if (a.comp_width == 2) return a.lookup == LK_DENSE ? run_u16_dense(a, occ) : run_u16_packed(a, occ);
   return a.lookup == LK_SPLIT ? run_u32_split(a, occ) : run_u32_packed(a, occ);
 }
@@ -76,6 +79,8 @@ struct DeviceIndex {
   uint32_t max_lds = 0;
   std::vector<uint32_t> list_nb, list_np;   // blocks / postings per posting list (host copy)
   uint32_t max_nb = 0;
+  uint32_t value_type = SGPU_VAL_F16;   // how the records store document values
+  float val_scale = 0.0f;
   bool fwd_block_major = false;   // forward store holds a copy of every posting's record, block by block
   static constexpr int kMainEvents = 64, kPool = 4;
   Lane main;
@@ -169,14 +174,14 @@ int device_count() {
 __global__ __launch_bounds__(256) void replicate_records_kernel(uint8_t* fwd, const uint64_t* __restrict__ doc_ref,
                                                                 const uint32_t* __restrict__ post_doc,
                                                                 const uint64_t* __restrict__ post_ref, uint64_t n_postings,
-                                                                uint32_t unit16_per_elem8) {
+                                                                uint32_t bytes_per_elem) {
   const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const uint32_t sub = threadIdx.x & 15;
   const uint64_t n_groups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
   for (uint64_t p = g; p < n_postings; p += n_groups) {
     const uint64_t dst = post_ref[p], src = doc_ref[post_doc[p]];
     const uint32_t len = (uint32_t)(dst & 0xffffu);
-    const uint32_t n16 = ((len + 7u) >> 3) * unit16_per_elem8;   // 16-byte units of the record
+    const uint32_t n16 = (((len + 7u) & ~7u) * bytes_per_elem + 15u) >> 4;   // 16-byte units of the record
     const uint4* s4 = (const uint4*)(fwd + (src >> 16) * 16ull);
     uint4* d4 = (uint4*)(fwd + (dst >> 16) * 16ull);
     for (uint32_t i = sub; i < n16; i += 16) d4[i] = s4[i];
@@ -209,8 +214,11 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     if ((st = lane_init(&l, 1)) != SGPU_OK) return bail(st);
 
   try {
-    const uint32_t cw = h.comp_width;
-    // ---- document records: [npad comps][npad f16], npad = len rounded up to 8, 16-byte aligned
+    const uint32_t cw = h.comp_width, vb = h.val_bytes();
+    d->value_type = h.value_type;
+    d->val_scale = h.val_scale;
+    // ---- document records: [npad comps][npad values (f16, or u8 codes)], npad = len rounded up to 8, the
+    // record padded to 16 bytes
     // A record is moved to the next 128-byte line only if it would otherwise touch more lines than
     // its size needs: at 16-byte alignment a 480-byte record straddles ~4.75 lines, line-fitted 4
     // (less HBM traffic per scored document; the run time is the same).
@@ -222,7 +230,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       for (uint64_t doc = 0; doc < h.n_docs; ++doc) {
         const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
         const uint64_t npad = (len + 7) & ~7ull;
-        const uint64_t size16 = npad * (cw + 2) / 16;
+        const uint64_t size16 = (npad * (cw + vb) + 15) / 16;
         const uint64_t in_line = cur % line16;
         if (size16 && (in_line + size16 + line16 - 1) / line16 > (size16 + line16 - 1) / line16)
           cur += line16 - in_line;
@@ -239,7 +247,8 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       const uint64_t npad = (len + 7) & ~7ull;
       uint8_t* rec = fwd.data() + rec_off16[(size_t)doc] * 16;
       std::memcpy(rec, h.fwd_comps.data() + s0 * cw, len * cw);
-      std::memcpy(rec + npad * cw, h.fwd_vals.data() + s0, len * 2);
+      if (vb == 2) std::memcpy(rec + npad * cw, h.fwd_vals.data() + s0, len * 2);
+      else std::memcpy(rec + npad * cw, h.fwd_codes.data() + s0, len);
       // padding components carry the sentinel id `dim` (never a query component) when it is
       // representable; their values are 0. The dense lookup path relies on it, the bitmap path
       // tests the length instead.
@@ -270,7 +279,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
         for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
           const uint32_t doc = h.post_doc[p];
           const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
-          u += ((len + 7) & ~7ull) * (cw + 2) / 16;
+          u += (((len + 7) & ~7ull) * (cw + vb) + 15) / 16;
         }
         bsize[(size_t)b + 1] = (u + 7) & ~7ull;   // blocks start on 128-byte lines
       }
@@ -298,7 +307,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
             const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
             if ((len > 128) != (cls == 1)) continue;
             pref[p] = ((block_major ? cur : rec_off16[doc]) << 16) | len;
-            cur += ((len + 7) & ~7ull) * (cw + 2) / 16;
+            cur += (((len + 7) & ~7ull) * (cw + vb) + 15) / 16;
           }
       }
       const uint64_t total_units = block_major ? blk_base + blk_units : doc_units;
@@ -325,7 +334,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     if (d->fwd_block_major && h.n_postings()) {
       hipLaunchKernelGGL(replicate_records_kernel, dim3(d->n_cu * 8), dim3(256), 0, d->main.stream,
                          (uint8_t*)d->view.fwd, d->view.doc_ref, d->view.post_doc, d->view.post_ref,
-                         (uint64_t)h.n_postings(), (uint32_t)(8 * (cw + 2) / 16));
+                         (uint64_t)h.n_postings(), (uint32_t)(cw + vb));
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(d->main.stream));
     }
@@ -431,6 +440,8 @@ sgpu_status device_index_clone(const DeviceIndex* src, int device, DeviceIndex**
   d->list_np = src->list_np;
   d->max_nb = src->max_nb;
   d->fwd_block_major = src->fwd_block_major;
+  d->value_type = src->value_type;
+  d->val_scale = src->val_scale;
   auto bail = [&](sgpu_status s) {
     device_index_free(d);
     return s;
@@ -722,6 +733,11 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   uint64_t o = 0;
   L.q_comp = (uint32_t)o; o += up((uint64_t)qn * 4);
   L.q_val = (uint32_t)o; o += up(((uint64_t)qn + 1) * 4);   // + the 0.0 slot non-matching components resolve to
+  L.q_sc = L.q_val;   // fixed-u8 documents: a second copy of the weights, scaled by val_scale
+  if (d->value_type == SGPU_VAL_FIXEDU8) {
+    L.q_sc = (uint32_t)o;
+    o += up(((uint64_t)qn + 1) * 4);
+  }
   L.sel = (uint32_t)o; o += up((6ull * qc + 1) * 4);
   if (o + up((uint64_t)qc * qn * 8) > lds_limit)
     return fail(SGPU_ELIMIT, "query_cut %u x %u query components do not fit the row tables in LDS", qc, qn);
@@ -816,6 +832,8 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->p.items_min = std::min<uint32_t>(a->p.items_init, env_u32("SGPU_ITEMS_MIN", 64));
   a->p.rblocks_max = std::min<uint32_t>(32, std::max<uint32_t>(1, env_u32("SGPU_RBLOCKS", 8)));   // one mask bit per block
   a->p.target_list = mode == MODE_DOTS ? sp.query_cut : 0;
+  a->p.val_scale = d->val_scale;
+  a->value_type = d->value_type;
   a->ix = d->view;
   a->comp_width = d->comp_width;
   a->block = NT;
@@ -847,7 +865,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   // occupancy of this kernel variant at this LDS size: queried once, then remembered
   int per_cu = 0;
   {
-    const uint64_t key = ((uint64_t)a->comp_width << 56) | ((uint64_t)a->counted << 55) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
+    const uint64_t key = ((uint64_t)a->comp_width << 56) | ((uint64_t)a->counted << 55) | ((uint64_t)a->value_type << 54) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
                          ((uint64_t)heap_variant(a->p.k) << 28) | (uint64_t)(a->lds_bytes >> 4);
     auto it = d->occupancy.find(key);
     if (it == d->occupancy.end()) {
@@ -1081,7 +1099,7 @@ sgpu_status build_knn_on_device(DeviceIndex* d, HostIndex& h, uint32_t nknn) {
     for (uint32_t q = 0; q <= nq; ++q) q_off[q] = h.fwd_offsets[d0 + q] - e0;
     for (uint64_t i = e0; i < e1; ++i) {
       q_comp[i - e0] = h.comp(i);
-      q_val[i - e0] = f16_to_f32(h.fwd_vals[i]);
+      q_val[i - e0] = h.val(i);
     }
     sgpu_batch* b = nullptr;
     st = batch_create(d, &d->main, h.dim, q_off.data(), q_comp.data(), q_val.data(), nq, k, &b);

@@ -62,10 +62,11 @@ struct KParams {
   uint32_t rblocks_max;  // blocks filtered per thread and round
   uint32_t n_knn;        // neighbours of each result to rescore after the lists (Knn::refine); 0 = off
   uint32_t target_list;  // MODE_DOTS: the posting list whose summary dots are wanted
+  float val_scale;       // fixed-u8 document values: value = code * val_scale (a power of two)
 };
 
 struct LdsLayout {   // byte offsets into dynamic LDS, all multiples of 16
-  uint32_t q_comp, q_val, q_bits, q_rank, sel, rt_start, rt_mid, rt_pre, dots, order, uni, part, heap, st;
+  uint32_t q_comp, q_val, q_sc, q_bits, q_rank, sel, rt_start, rt_mid, rt_pre, dots, order, uni, part, heap, st;
   uint32_t qc, qn;   // capacities: lists per query, components per query
   uint32_t dots_cap; // block dots that fit the dots area: a query's lists are processed in groups of at most this many blocks
   uint32_t total;
@@ -80,6 +81,7 @@ struct LaunchArgs {
   uint32_t* bitmaps;
   uint32_t comp_width, grid, block, lds_bytes;
   uint32_t lookup;  // LK_*: layout of the query lookup table in LDS
+  uint32_t value_type; // SGPU_VAL_*: how the records store document values
   uint32_t counted; // 1: the accounting variant of the kernel (visited bitmap in HBM, exact work counters)
   hipStream_t stream;
 };

@@ -36,14 +36,14 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
     for (uint64_t i = 0; i < nnz; ++i) ptr[ix.comp(i) + 1]++;
     for (uint64_t c = 0; c < ix.dim; ++c) ptr[c + 1] += ptr[c];
     std::vector<uint32_t> idoc(nnz);
-    std::vector<uint16_t> ival(nnz);
+    std::vector<float> ival(nnz);   // document values widened once (exact for f16 and fixed-u8)
     {
       std::vector<uint64_t> cur(ptr.begin(), ptr.end() - 1);
       for (uint64_t d = 0; d < ix.n_docs; ++d)
         for (uint64_t i = ix.fwd_offsets[d]; i < ix.fwd_offsets[d + 1]; ++i) {
           const uint64_t p = cur[ix.comp(i)]++;
           idoc[p] = (uint32_t)d;
-          ival[p] = ix.fwd_vals[i];
+          ival[p] = ix.val(i);
         }
     }
 #pragma omp parallel num_threads(nt)
@@ -63,7 +63,7 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
               seen[d] = 1;
               touched.push_back(d);
             }
-            acc[d] = acc[d] + qv * f16_to_f32(ival[p]);
+            acc[d] = acc[d] + qv * ival[p];
           }
         }
         cand.clear();

@@ -7,6 +7,7 @@
 #include "host_index.hpp"
 
 #include <cerrno>
+#include <cmath>
 #include <cstdlib>
 #include <exception>
 
@@ -30,6 +31,8 @@ sgpu_status fail(sgpu_status st, const char* fmt, ...) {
 void HostIndex::fill_desc(sgpu_index_desc* d) const {
   std::memset(d, 0, sizeof *d);
   d->comp_width = comp_width;
+  d->value_type = value_type;
+  d->val_scale = value_type == SGPU_VAL_F16 ? 0.0f : val_scale;
   d->n_docs = n_docs;
   d->dim = dim;
   d->nnz = nnz();
@@ -39,7 +42,7 @@ void HostIndex::fill_desc(sgpu_index_desc* d) const {
   d->n_entries = n_entries();
   d->fwd_offsets = fwd_offsets.data();
   d->fwd_comps = fwd_comps.data();
-  d->fwd_vals = fwd_vals.data();
+  d->fwd_vals = value_type == SGPU_VAL_F16 ? (const void*)fwd_vals.data() : (const void*)fwd_codes.data();
   d->list_block_start = list_block_start.data();
   d->block_post_start = block_post_start.data();
   d->post_doc = post_doc.data();
@@ -62,6 +65,12 @@ static bool monotone(const uint64_t* a, uint64_t n_plus_1, uint64_t last) {
 sgpu_status validate_desc(const sgpu_index_desc& d) {
   if (d.comp_width != 2 && d.comp_width != 4) return fail(SGPU_EINVAL, "comp_width must be 2 or 4");
   if (d.dim == 0) return fail(SGPU_EINVAL, "dim == 0");
+  if (d.value_type != SGPU_VAL_F16 && d.value_type != SGPU_VAL_FIXEDU8) return fail(SGPU_EINVAL, "unknown value_type %u", d.value_type);
+  if (d.value_type == SGPU_VAL_FIXEDU8) {
+    int e = 0;
+    if (!(d.val_scale > 0.0f) || std::frexp(d.val_scale, &e) != 0.5f) return fail(SGPU_EINVAL, "val_scale must be a positive power of two");
+    if (d.comp_width != 2) return fail(SGPU_EINVAL, "fixed-u8 values need u16 components (as the reference's DotVByte index does)");
+  }
   if (d.comp_width == 2 && d.dim > 65536) return fail(SGPU_EINVAL, "dim %llu does not fit u16 components", (unsigned long long)d.dim);
   if (d.dim > 0xffffffffull || d.n_docs > 0x7fffffffull) return fail(SGPU_EINVAL, "dim/n_docs out of range");
   if (!d.fwd_offsets || !d.list_block_start || !d.block_post_start || !d.list_row_start || !d.row_ptr)
@@ -115,7 +124,10 @@ sgpu_status host_index_from_desc(const sgpu_index_desc& d, HostIndex* out) {
     h.dim = d.dim;
     h.fwd_offsets.assign(d.fwd_offsets, d.fwd_offsets + d.n_docs + 1);
     h.fwd_comps.assign((const uint8_t*)d.fwd_comps, (const uint8_t*)d.fwd_comps + d.nnz * d.comp_width);
-    h.fwd_vals.assign(d.fwd_vals, d.fwd_vals + d.nnz);
+    h.value_type = d.value_type;
+    h.val_scale = d.value_type == SGPU_VAL_F16 ? 0.0f : d.val_scale;
+    if (d.value_type == SGPU_VAL_F16) h.fwd_vals.assign((const uint16_t*)d.fwd_vals, (const uint16_t*)d.fwd_vals + d.nnz);
+    else h.fwd_codes.assign((const uint8_t*)d.fwd_vals, (const uint8_t*)d.fwd_vals + d.nnz);
     h.list_block_start.assign(d.list_block_start, d.list_block_start + d.dim + 1);
     h.block_post_start.assign(d.block_post_start, d.block_post_start + d.n_blocks + 1);
     h.post_doc.assign(d.post_doc, d.post_doc + d.n_postings);
@@ -132,8 +144,9 @@ sgpu_status host_index_from_desc(const sgpu_index_desc& d, HostIndex* out) {
   return SGPU_OK;
 }
 
-// ---- file format: "SGPUIDX1", header of 10 u64, then the arrays in desc order ----
-static const char kMagic[8] = {'S', 'G', 'P', 'U', 'I', 'D', 'X', '1'};
+// ---- file format: "SGPUIDX2", header of 12 u64, then the arrays in desc order (+ the kNN graph) ----
+static const char kMagic[8] = {'S', 'G', 'P', 'U', 'I', 'D', 'X', '2'};
+static constexpr int kHdr = 12;
 
 template <class T>
 static bool wr(FILE* f, const std::vector<T>& v) {
@@ -150,10 +163,13 @@ sgpu_status host_index_save(const HostIndex& ix, const char* path) {
   if (!f) return fail(SGPU_EIO, "cannot open %s for writing: %s", path, strerror(errno));
   // hdr[8] = neighbours per document, hdr[9] = total neighbour ids of the kNN graph (0, 0 = no graph);
   // the reference serialises InvertedIndexBase{.., knn} in one file too (src/inverted_index.rs:39-52)
-  uint64_t hdr[10] = {ix.comp_width,   ix.n_docs,   ix.dim,         ix.nnz(),   ix.n_blocks(),
-                      ix.n_postings(), ix.n_rows(), ix.n_entries(), ix.knn_dim, ix.knn.size()};
-  bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, 8, 10, f) == 10 && wr(f, ix.fwd_offsets) &&
-            wr(f, ix.fwd_comps) && wr(f, ix.fwd_vals) && wr(f, ix.list_block_start) &&
+  uint32_t scale_bits = 0;
+  std::memcpy(&scale_bits, &ix.val_scale, 4);
+  uint64_t hdr[kHdr] = {ix.comp_width,   ix.n_docs,   ix.dim,         ix.nnz(),   ix.n_blocks(),
+                        ix.n_postings(), ix.n_rows(), ix.n_entries(), ix.knn_dim, ix.knn.size(),
+                        ix.value_type,   scale_bits};
+  bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, 8, kHdr, f) == kHdr && wr(f, ix.fwd_offsets) &&
+            wr(f, ix.fwd_comps) && wr(f, ix.fwd_vals) && wr(f, ix.fwd_codes) && wr(f, ix.list_block_start) &&
             wr(f, ix.block_post_start) && wr(f, ix.post_doc) && wr(f, ix.blk_min) && wr(f, ix.blk_quant) &&
             wr(f, ix.list_row_start) && wr(f, ix.row_comp) && wr(f, ix.row_ptr) && wr(f, ix.sum_bid) &&
             wr(f, ix.sum_code) && wr(f, ix.knn);
@@ -166,17 +182,23 @@ sgpu_status host_index_load(const char* path, HostIndex* out) {
   FILE* f = fopen(path, "rb");
   if (!f) return fail(SGPU_EIO, "cannot open %s: %s", path, strerror(errno));
   char magic[8];
-  uint64_t hdr[10];
-  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kMagic, 8) != 0 || fread(hdr, 8, 10, f) != 10) {
+  uint64_t hdr[kHdr];
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kMagic, 8) != 0 || fread(hdr, 8, kHdr, f) != kHdr) {
     fclose(f);
-    return fail(SGPU_EIO, "%s is not an SGPUIDX1 index file", path);
+    return fail(SGPU_EIO, "%s is not an SGPUIDX2 index file", path);
   }
   HostIndex& h = *out;
   h.comp_width = (uint32_t)hdr[0];
   h.n_docs = hdr[1];
   h.dim = hdr[2];
   const uint64_t nnz = hdr[3], nb = hdr[4], np = hdr[5], nr = hdr[6], ne = hdr[7], knn_dim = hdr[8], nk = hdr[9];
-  bool ok = (h.comp_width == 2 || h.comp_width == 4);
+  h.value_type = (uint32_t)hdr[10];
+  {
+    const uint32_t scale_bits = (uint32_t)hdr[11];
+    std::memcpy(&h.val_scale, &scale_bits, 4);
+  }
+  bool ok = (h.comp_width == 2 || h.comp_width == 4) && (h.value_type == SGPU_VAL_F16 || h.value_type == SGPU_VAL_FIXEDU8);
+  const uint64_t vb = h.value_type == SGPU_VAL_F16 ? 2 : 1;
   // the header is untrusted: the counts must add up to the file's size before anything is resized
   if (ok) {
     const uint64_t lim = 1ull << 48;
@@ -188,7 +210,7 @@ sgpu_status host_index_load(const char* path, HostIndex* out) {
     ok = ok && end >= 0 && fseek(f, pos, SEEK_SET) == 0;
     if (ok) {
       const uint64_t cw = h.comp_width;
-      const uint64_t need = 8 * (h.n_docs + 1) + nnz * cw + nnz * 2 + 8 * (h.dim + 1) + 8 * (nb + 1) + 4 * np + 8 * nb +
+      const uint64_t need = 8 * (h.n_docs + 1) + nnz * cw + nnz * vb + 8 * (h.dim + 1) + 8 * (nb + 1) + 4 * np + 8 * nb +
                             8 * (h.dim + 1) + nr * cw + 8 * (nr + 1) + 3 * ne + 4 * nk;
       ok = (uint64_t)(end - pos) == need;
     }
@@ -199,7 +221,8 @@ sgpu_status host_index_load(const char* path, HostIndex* out) {
   }
   try {
     ok = rd(f, h.fwd_offsets, h.n_docs + 1) && rd(f, h.fwd_comps, nnz * h.comp_width) &&
-         rd(f, h.fwd_vals, nnz) && rd(f, h.list_block_start, h.dim + 1) && rd(f, h.block_post_start, nb + 1) &&
+         rd(f, h.fwd_vals, vb == 2 ? nnz : 0) && rd(f, h.fwd_codes, vb == 1 ? nnz : 0) &&
+         rd(f, h.list_block_start, h.dim + 1) && rd(f, h.block_post_start, nb + 1) &&
          rd(f, h.post_doc, np) && rd(f, h.blk_min, nb) && rd(f, h.blk_quant, nb) &&
          rd(f, h.list_row_start, h.dim + 1) && rd(f, h.row_comp, nr * h.comp_width) && rd(f, h.row_ptr, nr + 1) &&
          rd(f, h.sum_bid, ne) && rd(f, h.sum_code, ne) && rd(f, h.knn, nk);
@@ -218,6 +241,49 @@ sgpu_status host_index_load(const char* path, HostIndex* out) {
   sgpu_index_desc d;
   h.fill_desc(&d);
   return validate_desc(d);
+}
+
+// InvertedIndexBase::convert_dataset_into: same lists / blocks / summaries, the forward index re-encoded.
+sgpu_status host_index_convert(const HostIndex& src, uint32_t value_type, HostIndex* out) {
+  if (value_type != SGPU_VAL_F16 && value_type != SGPU_VAL_FIXEDU8) return fail(SGPU_EINVAL, "unknown value_type %u", value_type);
+  if (value_type == SGPU_VAL_FIXEDU8 && src.comp_width != 2)
+    return fail(SGPU_EINVAL, "fixed-u8 values need u16 components (SeismicIndexDotVByte supports u16 only, src/pylib/dotvbyte.rs:20-27)");
+  try {
+    *out = src;
+    HostIndex& h = *out;
+    const uint64_t nnz = src.nnz();
+    if (value_type == src.value_type) return SGPU_OK;
+    if (value_type == SGPU_VAL_FIXEDU8) {
+      // [restated, parity unpinned] step = smallest power of two with 255 * step >= max value
+      float vmax = 0.0f;
+      for (uint64_t i = 0; i < nnz; ++i) {
+        const float v = src.val(i);
+        if (v > vmax) vmax = v;
+      }
+      float step = 0.00390625f;   // 2^-8: Q0.8
+      while (255.0f * step < vmax) step *= 2.0f;
+      h.value_type = SGPU_VAL_FIXEDU8;
+      h.val_scale = step;
+      h.fwd_codes.resize(nnz);
+      h.fwd_vals.clear();
+      h.fwd_vals.shrink_to_fit();
+#pragma omp parallel for schedule(static)
+      for (int64_t i = 0; i < (int64_t)nnz; ++i) {
+        const float r = std::round(src.val((uint64_t)i) / step);   // exact division (power of two); half away from zero
+        h.fwd_codes[(size_t)i] = r >= 255.0f ? 255 : (r > 0.0f ? (uint8_t)r : 0);
+      }
+    } else {
+      h.value_type = SGPU_VAL_F16;
+      h.val_scale = 0.0f;
+      h.fwd_vals.resize(nnz);
+      for (uint64_t i = 0; i < nnz; ++i) h.fwd_vals[i] = f32_to_f16_sat(src.val(i));
+      h.fwd_codes.clear();
+      h.fwd_codes.shrink_to_fit();
+    }
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of host memory converting the index");
+  }
+  return SGPU_OK;
 }
 
 }  // namespace sgpu

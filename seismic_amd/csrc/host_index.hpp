@@ -14,7 +14,10 @@ struct HostIndex {
   uint64_t n_docs = 0, dim = 0;
   std::vector<uint64_t> fwd_offsets;
   std::vector<uint8_t> fwd_comps;  // nnz * comp_width bytes
-  std::vector<uint16_t> fwd_vals;
+  std::vector<uint16_t> fwd_vals;   // value_type F16: binary16 bits
+  std::vector<uint8_t> fwd_codes;   // value_type FIXEDU8: value = code * val_scale
+  uint32_t value_type = SGPU_VAL_F16;
+  float val_scale = 0.0f;
   std::vector<uint64_t> list_block_start, block_post_start;
   std::vector<uint32_t> post_doc;
   std::vector<float> blk_min, blk_quant;
@@ -37,6 +40,10 @@ struct HostIndex {
     return comp_width == 2 ? (uint32_t)((const uint16_t*)fwd_comps.data())[i]
                            : ((const uint32_t*)fwd_comps.data())[i];
   }
+  inline float val(uint64_t i) const {   // document value i as f32 (exact for both value types)
+    return value_type == SGPU_VAL_F16 ? f16_to_f32(fwd_vals[i]) : (float)fwd_codes[i] * val_scale;
+  }
+  inline uint32_t val_bytes() const { return value_type == SGPU_VAL_F16 ? 2u : 1u; }
   inline uint32_t rcomp(uint64_t i) const {
     return comp_width == 2 ? (uint32_t)((const uint16_t*)row_comp.data())[i]
                            : ((const uint32_t*)row_comp.data())[i];
@@ -49,6 +56,7 @@ sgpu_status validate_desc(const sgpu_index_desc& d);
 sgpu_status host_index_from_desc(const sgpu_index_desc& d, HostIndex* out);
 sgpu_status host_index_save(const HostIndex& ix, const char* path);
 sgpu_status host_index_load(const char* path, HostIndex* out);
+sgpu_status host_index_convert(const HostIndex& src, uint32_t value_type, HostIndex* out);
 
 // builder.cpp
 sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim, const uint64_t* offsets,

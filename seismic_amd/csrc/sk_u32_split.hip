@@ -1,6 +1,6 @@
-// sk_u32_split.hip — the search kernel family for uint32_t components with the LK_SPLIT query lookup table.
+// sk_u32_split.hip — the search kernel family for uint32_t components with the LK_SPLIT query lookup table, f16 values.
 #include "search_kernel.inc"
 
 namespace sgpu {
-hipError_t run_u32_split(const LaunchArgs& a, int* occupancy) { return run_family<uint32_t, LK_SPLIT>(a, occupancy); }
+hipError_t run_u32_split(const LaunchArgs& a, int* occupancy) { return run_family<uint32_t, LK_SPLIT, VT_F16>(a, occupancy); }
 }  // namespace sgpu

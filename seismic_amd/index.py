@@ -422,6 +422,23 @@ class SeismicIndexLV(_IndexBase):
     _CW = 4
 
 
+class SeismicIndexDotVByte(_IndexBase):
+    """The reference's compressed index (src/pylib/dotvbyte.rs:20-36): the standard u16/f16 index is
+    built first and its forward index is then converted (`convert_dataset_into`, :208-213) - here to
+    fixed-u8 document values, 3 bytes per component instead of 4 in HBM. Same query API and results
+    type as SeismicIndex; scores differ by the 8-bit quantisation of the document values. u16
+    components only, as in the reference. (vectorium's DotVByteFixedU8Encoder is not in the reference
+    tree: the fixed-point step is restated, see include/seismic_hip.h; its variable-byte component
+    stream is a lossless storage codec without arithmetic and is not reproduced.)"""
+    _CW = 2
+
+    def __init__(self, native, token_map, doc_ids, contents=None, device=0, upload=True):
+        from ._abi import SGPU_VAL_FIXEDU8
+        if native.desc.value_type != SGPU_VAL_FIXEDU8:
+            native = native.convert(SGPU_VAL_FIXEDU8)
+        super().__init__(native, token_map, doc_ids, contents, device, upload)
+
+
 # ---------------------------------------------------------------------------
 class _RawBase:
     """Integer-keyed index over the inner binary format (reference src/pylib/mod.rs:663-1151)."""

@@ -37,6 +37,8 @@ def lib():
                                       C.c_void_p, C.POINTER(BuildConfig)]
         L.orc_index_desc.argtypes = [C.c_void_p, C.POINTER(IndexDesc)]
         L.orc_index_free.argtypes = [C.c_void_p]
+        L.orc_index_convert_fixedu8.restype = C.c_void_p
+        L.orc_index_convert_fixedu8.argtypes = [C.c_void_p]
         L.orc_f16_to_f32.restype = C.c_float
         L.orc_f16_to_f32.argtypes = [C.c_uint16]
         L.orc_f32_to_f16.restype = C.c_uint16
@@ -75,6 +77,15 @@ class OracleIndex:
         self.desc = IndexDesc()
         lib().orc_index_desc(self.h, C.byref(self.desc))
 
+    def convert_fixedu8(self):
+        """convert_dataset_into (reference src/pylib/dotvbyte.rs:208-213) restated: fixed-u8 forward values."""
+        o = object.__new__(OracleIndex)
+        o.cfg, o._keep = self.cfg, self._keep
+        o.h = lib().orc_index_convert_fixedu8(self.h)
+        o.desc = IndexDesc()
+        lib().orc_index_desc(o.h, C.byref(o.desc))
+        return o
+
     def __del__(self):
         if getattr(self, "h", None):
             lib().orc_index_free(self.h)
@@ -92,7 +103,7 @@ def desc_arrays(desc):
     return dict(
         fwd_offsets=arr(desc.fwd_offsets, desc.n_docs + 1, np.uint64),
         fwd_comps=arr(desc.fwd_comps, desc.nnz, cw),
-        fwd_vals=arr(desc.fwd_vals, desc.nnz, np.uint16),
+        fwd_vals=arr(desc.fwd_vals, desc.nnz, np.uint16 if desc.value_type == 0 else np.uint8),
         list_block_start=arr(desc.list_block_start, desc.dim + 1, np.uint64),
         block_post_start=arr(desc.block_post_start, desc.n_blocks + 1, np.uint64),
         post_doc=arr(desc.post_doc, desc.n_postings, np.uint32),

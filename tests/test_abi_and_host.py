@@ -25,12 +25,12 @@ def test_every_declared_symbol_is_exported():
     L = ctypes.CDLL(_native.LIB_PATH)
     missing = [n for n in sorted(names) if not hasattr(L, n)]
     assert not missing, missing
-    assert L.sgpu_abi_version() == 2
+    assert L.sgpu_abi_version() == 3
 
 
 def test_struct_layouts_match_header_sizes():
     # sizes implied by the header's field lists (natural alignment)
-    assert ctypes.sizeof(IndexDesc) == 8 + 7 * 8 + 13 * 8
+    assert ctypes.sizeof(IndexDesc) == 8 + 7 * 8 + 13 * 8 + 8
     assert ctypes.sizeof(BuildConfig) == 32
     assert ctypes.sizeof(_native.SearchParams) == 20
     assert ctypes.sizeof(_native.LaunchStats) == 20
@@ -268,3 +268,41 @@ def test_inner_format_against_bytes_written_by_the_reference_converter(tmp_path)
     open(str(tmp_path / "trunc.bin"), "wb").write(open(os.path.join(gold, "documents.bin"), "rb").read()[:1000])
     with pytest.raises(IOError):
         seismic_amd.read_inner_format(str(tmp_path / "trunc.bin"))
+
+
+def test_convert_to_fixed_u8_host_side(tmp_path):
+    """sgpu_index_convert (the reference's convert_dataset_into, src/pylib/dotvbyte.rs:208-213): same lists,
+    blocks and summaries; forward values become u8 codes with a power-of-two step; identical to the oracle's
+    restatement; survives save/load; exact search over the converted index equals the oracle's."""
+    dim = 150
+    off, comps, vals = random_dataset(91, 2000, dim, nnz_lo=5, nnz_hi=60)
+    cfg = BuildConfig.defaults(n_postings=40)
+    ix = _native.NativeIndex.build(2, dim, off, comps, vals, cfg)
+    u8 = ix.convert(1)
+    oix = orc.OracleIndex(2, dim, off, comps, vals, cfg).convert_fixedu8()
+    from util import desc_equal
+    desc_equal(u8.desc, oix.desc)
+    assert u8.desc.value_type == 1 and u8.desc.val_scale == oix.desc.val_scale
+    import math
+    assert math.frexp(u8.desc.val_scale)[0] == 0.5                       # a power of two
+    a, b = orc.desc_arrays(ix.desc), orc.desc_arrays(u8.desc)
+    for k_ in a:
+        if k_ != "fwd_vals":
+            assert np.array_equal(a[k_], b[k_]), k_
+    f16 = a["fwd_vals"].view(np.float16).astype(np.float32)
+    deq = b["fwd_vals"].astype(np.float32) * np.float32(u8.desc.val_scale)
+    assert b["fwd_vals"].dtype == np.uint8 and np.abs(deq - f16).max() <= u8.desc.val_scale / 2 + 1e-7
+    assert 255 * u8.desc.val_scale >= f16.max() > 255 * u8.desc.val_scale / 2
+    p = str(tmp_path / "u8.idx")
+    u8.save(p)
+    loaded = _native.NativeIndex.load(p)
+    desc_equal(loaded.desc, u8.desc)
+    q_off, qc, qv = random_queries(92, 12, dim, 5, 40)
+    sc, ids, n = u8.exact_search(q_off, qc, qv, 10)
+    for i in range(12):
+        es, ei = orc.exact_search(u8.desc, qc[q_off[i]:q_off[i + 1]], qv[q_off[i]:q_off[i + 1]], 10, orc.ORDER_SEQ)
+        assert np.array_equal(ids[i, :n[i]], ei) and np.array_equal(sc[i, :n[i]], es)
+    back = u8.convert(0)                                                  # and back to f16: values are the dequantised codes
+    assert back.desc.value_type == 0
+    with pytest.raises(_native.SeismicHipError):
+        _native.NativeIndex.build(4, 70000, *random_dataset(93, 50, 70000)).convert(1)   # u16 components only
