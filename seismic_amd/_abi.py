@@ -50,13 +50,15 @@ class BuildConfig(C.Structure):
         ("max_fraction", C.c_float),
         ("doc_cut", C.c_uint32),
         ("num_threads", C.c_uint32),
+        ("use_device", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
     @classmethod
     def defaults(cls, **kw):
         # reference Python defaults: src/pylib/mod.rs:329
         d = dict(n_postings=3500, centroid_fraction=0.1, min_cluster_size=2,
-                 summary_energy=0.4, max_fraction=1.5, doc_cut=15, num_threads=0)
+                 summary_energy=0.4, max_fraction=1.5, doc_cut=15, num_threads=0, use_device=0)
         d.update(kw)
         return cls(**d)
 

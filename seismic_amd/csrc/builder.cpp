@@ -26,6 +26,14 @@
 #include "host_index.hpp"
 
 namespace sgpu {
+// build_assign.hip: the clustering step on a HIP device
+uint32_t device_assign_max_centroids();
+sgpu_status device_assign_clusters(int device, uint32_t comp_width, uint64_t n_docs, uint64_t dim, uint64_t nnz,
+                                   const uint64_t* doc_off, const void* doc_comp, const uint16_t* doc_val,
+                                   const void* top, uint32_t doc_cut, uint32_t min_cluster_size,
+                                   const uint64_t* lp_off, const uint32_t* post, const uint64_t* lc_off,
+                                   const uint32_t* cent, const uint8_t* eligible, uint64_t inv_cap,
+                                   uint32_t* cid_out);
 namespace {
 
 struct Docs {
@@ -136,24 +144,30 @@ void assign_docs(const std::vector<uint32_t>& docs, const std::vector<uint32_t>&
   }
 }
 
-void build_list(const Docs& d, const std::vector<uint32_t>& postings_by_value, const sgpu_build_config& cfg,
-                const std::vector<TopC>& top, Scratch& s, ListOut& o) {
+// n_centroids of a list of `len` postings and the sampled centroid documents (src/posting_list.rs:241-246,
+// src/utils.rs:163-168; rand's choose_multiple restated as a partial Fisher-Yates over SplitMix64, seed 1142).
+void sample_centroids(const std::vector<uint32_t>& postings_by_value, const sgpu_build_config& cfg,
+                      std::vector<uint32_t>& centroid_docs) {
   const size_t len = postings_by_value.size();
-  if (len == 0) {
-    o.block_off.clear();
-    return;
-  }
-  // ---- blocking_with_random_kmeans (src/posting_list.rs:227-300) ----
   const size_t n_centroids = std::max<size_t>(1, (size_t)(cfg.centroid_fraction * (float)len));
   SplitMix64 rng(1142);  // seed of src/utils.rs:163
   std::vector<uint32_t> pool(postings_by_value);
   const size_t nc = std::min(n_centroids, len);
-  std::vector<uint32_t> centroid_docs(nc);
+  centroid_docs.resize(nc);
   for (size_t i = 0; i < nc; ++i) {
     const size_t j = i + (size_t)rng.below(len - i);
     std::swap(pool[i], pool[j]);
     centroid_docs[i] = pool[i];
   }
+}
+
+// do_random_kmeans_on_docids_ii_approx_dot_product (src/utils.rs:146-237) on the host: (centroid doc, doc)
+// pairs of the final assignment, unsorted.
+void cluster_list_cpu(const Docs& d, const std::vector<uint32_t>& postings_by_value, const std::vector<uint32_t>& centroid_docs,
+                      const sgpu_build_config& cfg, const std::vector<TopC>& top, Scratch& s,
+                      std::vector<std::pair<uint32_t, uint32_t>>& fin) {
+  const size_t len = postings_by_value.size();
+  const size_t nc = centroid_docs.size();
   // centroid inverted file
   s.touched_comps.clear();
   size_t total = 0;
@@ -191,7 +205,7 @@ void build_list(const Docs& d, const std::vector<uint32_t>& postings_by_value, c
   std::sort(assign.begin(), assign.end());
   // dissolve clusters with <= min_cluster_size members (src/utils.rs:196-209)
   std::vector<uint32_t> redo;
-  std::vector<std::pair<uint32_t, uint32_t>> fin;
+  fin.clear();
   fin.reserve(len);
   std::vector<std::pair<uint32_t, uint32_t>> cdoc_to_cid(nc);
   for (size_t i = 0; i < nc; ++i) cdoc_to_cid[i] = {centroid_docs[i], (uint32_t)i};
@@ -214,8 +228,14 @@ void build_list(const Docs& d, const std::vector<uint32_t>& postings_by_value, c
     assign_docs(redo, centroid_docs, top, cfg.doc_cut, s, re);
     fin.insert(fin.end(), re.begin(), re.end());
   }
-  std::sort(fin.begin(), fin.end());
   for (uint32_t c : s.touched_comps) s.comp_cnt[c] = 0;
+}
+
+// Blocks from the final (centroid doc, doc) pairs, then the per-block summaries and the list's summary CSR.
+void finish_list(const Docs& d, std::vector<std::pair<uint32_t, uint32_t>>& fin, const sgpu_build_config& cfg, Scratch& s,
+                 ListOut& o) {
+  const size_t len = fin.size();
+  std::sort(fin.begin(), fin.end());
 
   o.post.resize(len);
   o.block_off.assign(1, 0);
@@ -441,32 +461,84 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
       }
     }
 
-    // ---- per list ----
+    // ---- per list, phase 1: the postings kept (heaviest first) and the sampled centroids ----
+    std::vector<uint64_t> lp_off(dim + 1, 0), lc_off(dim + 1, 0);
+    for (uint64_t c = 0; c < dim; ++c) {
+      const size_t len = std::min<size_t>(list_cnt[c + 1] - list_cnt[c], cap);
+      if ((size_t)(cfg.centroid_fraction * (float)len) > 65535)   // src/posting_list.rs:243-246
+        return fail(SGPU_ELIMIT, "a posting list needs more than 65535 centroids; decrease centroid_fraction");
+      const size_t nc = len ? std::min(std::max<size_t>(1, (size_t)(cfg.centroid_fraction * (float)len)), len) : 0;
+      lp_off[c + 1] = lp_off[c] + len;
+      lc_off[c + 1] = lc_off[c] + nc;
+    }
+    std::vector<uint32_t> post_flat(lp_off[dim]), cent_flat(lc_off[dim]);
+    const bool on_device = cfg.use_device != 0;
+    std::vector<uint8_t> eligible(dim, 0);
+    uint64_t inv_cap = 0;
+#pragma omp parallel num_threads(nt)
+    {
+      std::vector<uint32_t> pl, cd;
+      uint64_t my_cap = 0;
+#pragma omp for schedule(dynamic, 8)
+      for (int64_t c = 0; c < (int64_t)dim; ++c) {
+        const uint64_t a = list_cnt[(size_t)c], b = list_cnt[(size_t)c + 1];
+        const size_t len = (size_t)(lp_off[(size_t)c + 1] - lp_off[(size_t)c]);
+        if (a == b || len == 0) continue;
+        std::sort(pairs.begin() + (long)a, pairs.begin() + (long)b);
+        pl.resize(len);
+        for (size_t i = 0; i < len; ++i) pl[i] = (uint32_t)(pairs[a + i] & 0xffffffffu);
+        std::copy(pl.begin(), pl.end(), post_flat.begin() + (long)lp_off[(size_t)c]);
+        sample_centroids(pl, cfg, cd);
+        std::copy(cd.begin(), cd.end(), cent_flat.begin() + (long)lc_off[(size_t)c]);
+        if (on_device && cd.size() <= device_assign_max_centroids()) {
+          eligible[(size_t)c] = 1;
+          uint64_t entries = 0;
+          for (uint32_t x : cd) entries += d.off[x + 1] - d.off[x];
+          my_cap = std::max(my_cap, entries);
+        }
+      }
+#pragma omp critical
+      inv_cap = std::max(inv_cap, my_cap);
+    }
+    pairs.clear();
+    pairs.shrink_to_fit();
+
+    // ---- phase 2: cluster assignment on the device (build_assign.hip) for the lists it can take ----
+    std::vector<uint32_t> cid_flat;
+    if (on_device) {
+      cid_flat.resize(post_flat.size());
+      sgpu_status dst = device_assign_clusters((int)cfg.use_device - 1, comp_width, n_docs, dim, nnz, h.fwd_offsets.data(),
+                                               h.fwd_comps.data(), h.fwd_vals.data(), top.data(), dc, cfg.min_cluster_size,
+                                               lp_off.data(), post_flat.data(), lc_off.data(), cent_flat.data(),
+                                               eligible.data(), inv_cap, cid_flat.data());
+      if (dst != SGPU_OK) return dst;   // no silent fall back to the host path
+    }
+
+    // ---- phase 3: blocks and summaries (and the clustering of the lists that stayed on the host) ----
     std::vector<ListOut> outs(dim);
-    std::atomic<int> limit_err{0};
 #pragma omp parallel num_threads(nt)
     {
       Scratch s(dim);
-      std::vector<uint32_t> pl;
+      std::vector<uint32_t> pl, cd;
+      std::vector<std::pair<uint32_t, uint32_t>> fin;
 #pragma omp for schedule(dynamic, 8)
       for (int64_t c = 0; c < (int64_t)dim; ++c) {
-        uint64_t a = list_cnt[(size_t)c], b = list_cnt[(size_t)c + 1];
-        if (a == b) continue;
-        std::sort(pairs.begin() + (long)a, pairs.begin() + (long)b);
-        const size_t len = std::min<size_t>(b - a, cap);
+        const size_t len = (size_t)(lp_off[(size_t)c + 1] - lp_off[(size_t)c]);
         if (len == 0) continue;
-        if ((size_t)(cfg.centroid_fraction * (float)len) > 65535) {
-          limit_err = 1;  // src/posting_list.rs:243-246
-          continue;
+        const uint32_t* pp = post_flat.data() + lp_off[(size_t)c];
+        const uint32_t* cp = cent_flat.data() + lc_off[(size_t)c];
+        if (eligible[(size_t)c]) {
+          const uint32_t* ci = cid_flat.data() + lp_off[(size_t)c];
+          fin.resize(len);
+          for (size_t i = 0; i < len; ++i) fin[i] = {cp[ci[i]], pp[i]};
+        } else {
+          pl.assign(pp, pp + len);
+          cd.assign(cp, cp + (lc_off[(size_t)c + 1] - lc_off[(size_t)c]));
+          cluster_list_cpu(d, pl, cd, cfg, top, s, fin);
         }
-        pl.resize(len);
-        for (size_t i = 0; i < len; ++i) pl[i] = (uint32_t)(pairs[a + i] & 0xffffffffu);
-        build_list(d, pl, cfg, top, s, outs[(size_t)c]);
+        finish_list(d, fin, cfg, s, outs[(size_t)c]);
       }
     }
-    if (limit_err) return fail(SGPU_ELIMIT, "a posting list needs more than 65535 centroids; decrease centroid_fraction");
-    pairs.clear();
-    pairs.shrink_to_fit();
     top.clear();
     top.shrink_to_fit();
 

@@ -169,10 +169,12 @@ def _resolve(tokens, values, token_map):
 
 
 def _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy, max_fraction, doc_cut, num_threads):
+    # SGPU_BUILD_DEVICE=<n>: run the clustering step of the build on HIP device n (byte-identical index)
+    dev = os.environ.get("SGPU_BUILD_DEVICE", "")
     return BuildConfig.defaults(n_postings=int(n_postings), centroid_fraction=float(centroid_fraction),
                                 min_cluster_size=int(min_cluster_size), summary_energy=float(summary_energy),
                                 max_fraction=float(max_fraction), doc_cut=int(doc_cut),
-                                num_threads=int(num_threads))
+                                num_threads=int(num_threads), use_device=int(dev) + 1 if dev else 0)
 
 
 def _no_knn_path(knn_path):

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported():
 def test_struct_layouts_match_header_sizes():
     # sizes implied by the header's field lists (natural alignment)
     assert ctypes.sizeof(IndexDesc) == 8 + 7 * 8 + 13 * 8 + 8
-    assert ctypes.sizeof(BuildConfig) == 32
+    assert ctypes.sizeof(BuildConfig) == 40
     assert ctypes.sizeof(_native.SearchParams) == 20
     assert ctypes.sizeof(_native.LaunchStats) == 20
 
