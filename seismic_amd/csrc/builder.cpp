@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 
 #ifdef _OPENMP
@@ -338,6 +339,13 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
 #else
   const int nt = 1;
 #endif
+  const bool debug = std::getenv("SGPU_DEBUG") != nullptr;
+  double t_last = omp_get_wtime();
+  auto lap = [&](const char* what) {
+    const double t = omp_get_wtime();
+    if (debug) std::fprintf(stderr, "sgpu build: %-28s %.2f s\n", what, t - t_last);
+    t_last = t;
+  };
   try {
     HostIndex& h = *out;
     h.comp_width = comp_width;
@@ -364,6 +372,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
     if (bad == 2) return fail(SGPU_EINVAL, "document components must be strictly ascending and < dim");
     if (bad == 3) return fail(SGPU_EINVAL, "NaN document value");
     Docs d{n_docs, dim, h.fwd_offsets.data(), wide.data(), h.fwd_vals.data()};
+    lap("ingest (f16 rounding)");
 
     // ---- global_threshold_pruning (src/inverted_index.rs:354-389) ----
     // top dim*n_postings entries by value; ties by (doc asc, comp asc) = scan order.
@@ -426,6 +435,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
     }
     sel.clear();
     sel.shrink_to_fit();
+    lap("global threshold pruning");
     const size_t cap = (size_t)((float)cfg.n_postings * cfg.max_fraction);
 
     // every document's doc_cut heaviest components (k_largest_by, src/utils.rs:125-127),
@@ -461,6 +471,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
       }
     }
 
+    lap("top components per doc");
     // ---- per list, phase 1: the postings kept (heaviest first) and the sampled centroids ----
     std::vector<uint64_t> lp_off(dim + 1, 0), lc_off(dim + 1, 0);
     for (uint64_t c = 0; c < dim; ++c) {
@@ -503,6 +514,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
     pairs.clear();
     pairs.shrink_to_fit();
 
+    lap("sort postings + centroids");
     // ---- phase 2: cluster assignment on the device (build_assign.hip) for the lists it can take ----
     std::vector<uint32_t> cid_flat;
     if (on_device) {
@@ -514,6 +526,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
       if (dst != SGPU_OK) return dst;   // no silent fall back to the host path
     }
 
+    lap("device clustering");
     // ---- phase 3: blocks and summaries (and the clustering of the lists that stayed on the host) ----
     std::vector<ListOut> outs(dim);
 #pragma omp parallel num_threads(nt)
@@ -541,6 +554,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
     }
     top.clear();
     top.shrink_to_fit();
+    lap("clustering (host) + summaries");
 
     // ---- concatenate ----
     h.list_block_start.assign(dim + 1, 0);
@@ -554,6 +568,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
       post_base[c + 1] = post_base[c] + o.post.size();
       ent_base[c + 1] = ent_base[c] + o.bid.size();
     }
+    lap("concat: offsets");
     const uint64_t NB = h.list_block_start[dim], NR = h.list_row_start[dim];
     h.block_post_start.assign(NB + 1, 0);
     h.post_doc.resize(post_base[dim]);
@@ -563,6 +578,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
     h.row_ptr.assign(NR + 1, 0);
     h.sum_bid.resize(ent_base[dim]);
     h.sum_code.resize(ent_base[dim]);
+    lap("concat: alloc");
 #pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
     for (int64_t c = 0; c < (int64_t)dim; ++c) {
       const ListOut& o = outs[(size_t)c];
@@ -582,6 +598,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
       std::copy(o.bid.begin(), o.bid.end(), h.sum_bid.begin() + (long)ent_base[(size_t)c]);
       std::copy(o.code.begin(), o.code.end(), h.sum_code.begin() + (long)ent_base[(size_t)c]);
     }
+    lap("concatenate");
     // block_post_start[b0] of an empty-list boundary: fill forward so the array is monotone
     // (entries written above are exact; index 0 stays 0 and every list's first block starts
     // at post_base[c], which equals the previous list's last value).
