@@ -73,8 +73,9 @@ def parse_args():
                     help="document value storage (fixedu8: the forward index of the reference's DotVByte index)")
     ap.add_argument("--sample", type=int, default=1000,
                     help="queries of the first timed batch used for recall, the oracle identity check and cpu_baseline")
-    ap.add_argument("--build-on-device", action="store_true",
-                    help="run the clustering step of the index build on the GPU (byte-identical index)")
+    ap.add_argument("--build-on-host", action="store_true",
+                    help="build the index on the host cores only (default: the clustering step runs on the GPU; "
+                         "the index is byte-identical either way)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-recall", action="store_true", help="skip recall@k vs exact")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement")
@@ -144,7 +145,7 @@ def main():
     cfg = BuildConfig.defaults(n_postings=args.n_postings, centroid_fraction=args.centroid_fraction,
                                summary_energy=args.summary_energy, max_fraction=args.max_fraction,
                                min_cluster_size=args.min_cluster_size, doc_cut=15,
-                               use_device=(local_rank + 1) if args.build_on_device else 0)
+                               use_device=0 if args.build_on_host else (local_rank + 1))
     src_tag = ("%d_%d" % (args.docs, args.dim)) if not args.documents else \
         ("file_%s_%d" % (os.path.basename(args.documents), os.path.getsize(args.documents)))
     tag = "sgpu2_%s_cw%d_np%d_cf%g_se%g_mf%g_mc%d" % (
