@@ -18,6 +18,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 #include <numeric>
 
 #ifdef _OPENMP
@@ -442,11 +443,16 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
     // computed once instead of once per posting
     const uint32_t dc = cfg.doc_cut;
     std::vector<TopC> top((size_t)n_docs * dc);
+    // allocations inside the parallel regions below cannot reach the enclosing try: the per-thread
+    // scratch is created before the regions, and every loop body catches and flags
+    std::atomic<int> oom{0};
+    std::vector<std::unique_ptr<Scratch>> scratch((size_t)nt);
+    for (auto& sp : scratch) sp.reset(new Scratch(dim));
 #pragma omp parallel num_threads(nt)
     {
       std::vector<std::pair<int32_t, uint32_t>> tmp;  // (-key, comp)
 #pragma omp for schedule(dynamic, 1024)
-      for (int64_t doc = 0; doc < (int64_t)n_docs; ++doc) {
+      for (int64_t doc = 0; doc < (int64_t)n_docs; ++doc) try {
         tmp.clear();
         for (uint64_t i = offsets[doc]; i < offsets[doc + 1]; ++i)
           tmp.emplace_back(total_key(f16_to_f32(h.fwd_vals[i])), wide[i]);
@@ -468,8 +474,11 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
             t[i].v = 0.0f;
           }
         }
+      } catch (const std::bad_alloc&) {
+        oom = 1;
       }
     }
+    if (oom) return fail(SGPU_ENOMEM, "out of host memory building the index");
 
     lap("top components per doc");
     // ---- per list, phase 1: the postings kept (heaviest first) and the sampled centroids ----
@@ -491,7 +500,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
       std::vector<uint32_t> pl, cd;
       uint64_t my_cap = 0;
 #pragma omp for schedule(dynamic, 8)
-      for (int64_t c = 0; c < (int64_t)dim; ++c) {
+      for (int64_t c = 0; c < (int64_t)dim; ++c) try {
         const uint64_t a = list_cnt[(size_t)c], b = list_cnt[(size_t)c + 1];
         const size_t len = (size_t)(lp_off[(size_t)c + 1] - lp_off[(size_t)c]);
         if (a == b || len == 0) continue;
@@ -507,10 +516,13 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
           for (uint32_t x : cd) entries += d.off[x + 1] - d.off[x];
           my_cap = std::max(my_cap, entries);
         }
+      } catch (const std::bad_alloc&) {
+        oom = 1;
       }
 #pragma omp critical
       inv_cap = std::max(inv_cap, my_cap);
     }
+    if (oom) return fail(SGPU_ENOMEM, "out of host memory building the index");
     pairs.clear();
     pairs.shrink_to_fit();
 
@@ -531,11 +543,15 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
     std::vector<ListOut> outs(dim);
 #pragma omp parallel num_threads(nt)
     {
-      Scratch s(dim);
+#ifdef _OPENMP
+      Scratch& s = *scratch[(size_t)omp_get_thread_num()];
+#else
+      Scratch& s = *scratch[0];
+#endif
       std::vector<uint32_t> pl, cd;
       std::vector<std::pair<uint32_t, uint32_t>> fin;
 #pragma omp for schedule(dynamic, 8)
-      for (int64_t c = 0; c < (int64_t)dim; ++c) {
+      for (int64_t c = 0; c < (int64_t)dim; ++c) try {
         const size_t len = (size_t)(lp_off[(size_t)c + 1] - lp_off[(size_t)c]);
         if (len == 0) continue;
         const uint32_t* pp = post_flat.data() + lp_off[(size_t)c];
@@ -550,8 +566,11 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
           cluster_list_cpu(d, pl, cd, cfg, top, s, fin);
         }
         finish_list(d, fin, cfg, s, outs[(size_t)c]);
+      } catch (const std::bad_alloc&) {
+        oom = 1;
       }
     }
+    if (oom) return fail(SGPU_ENOMEM, "out of host memory building the index");
     top.clear();
     top.shrink_to_fit();
     lap("clustering (host) + summaries");

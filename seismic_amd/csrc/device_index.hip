@@ -512,45 +512,6 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
   return (uint32_t)std::strtoul(v, nullptr, 10);
 }
 
-sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t* comps, const float* vals,
-                             uint32_t nq, uint32_t* max_nnz) {
-  if (!q_off || q_off[0] != 0) return fail(SGPU_EINVAL, "q_off[0] must be 0");
-  uint32_t mx = 0;
-  for (uint32_t q = 0; q < nq; ++q) {
-    if (q_off[q + 1] < q_off[q]) return fail(SGPU_EINVAL, "q_off not monotone");
-    const uint64_t n = q_off[q + 1] - q_off[q];
-    if (n > 0xffffu) return fail(SGPU_ELIMIT, "query %u has %llu components (limit 65535)", q, (unsigned long long)n);
-    mx = std::max<uint32_t>(mx, (uint32_t)n);
-  }
-  if (q_off[nq] >= 0xffffffffull) return fail(SGPU_ELIMIT, "batch too large");
-  if (q_off[nq] && (!comps || !vals)) return fail(SGPU_EINVAL, "null query arrays");
-  // InvertedIndexBase::search asserts sorted components (reference src/inverted_index.rs:172-175)
-  // and indexes posting_lists[component] (bounds panic, :193); duplicates are rejected too.
-  int bad_kind = 0;
-  uint32_t bad_q = 0xffffffffu;
-#pragma omp parallel for schedule(static) if (nq >= 2048)
-  for (int64_t q = 0; q < (int64_t)nq; ++q) {
-    int kind = 0;
-    for (uint64_t i = q_off[q]; i < q_off[q + 1] && !kind; ++i) {
-      if (comps[i] >= dim) kind = 1;
-      else if (i > q_off[q] && comps[i] <= comps[i - 1]) kind = 2;
-      else if (std::isnan(vals[i])) kind = 3;
-    }
-    if (kind) {
-#pragma omp critical
-      if ((uint32_t)q < bad_q) {
-        bad_q = (uint32_t)q;
-        bad_kind = kind;
-      }
-    }
-  }
-  if (bad_kind == 1) return fail(SGPU_EINVAL, "query %u: component >= dim", bad_q);
-  if (bad_kind == 2) return fail(SGPU_EINVAL, "query %u: components must be strictly ascending", bad_q);
-  if (bad_kind == 3) return fail(SGPU_EINVAL, "query %u: NaN value", bad_q);
-  *max_nnz = mx;
-  return SGPU_OK;
-}
-
 void batch_free(sgpu_batch* b) {
   if (!b) return;
   if (b->device >= 0) (void)hipSetDevice(b->device);

@@ -8,6 +8,7 @@
 // order (f32, no FMA), i.e. the sequential left-to-right dot product. Host code;
 // not on the hot path (used by bench.py and tests to measure recall).
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #ifdef _OPENMP
@@ -23,8 +24,11 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
                               float* out_scores, uint64_t* out_ids, uint32_t* out_n) {
   if (k == 0) return fail(SGPU_EINVAL, "k == 0");
   const uint64_t nnz = ix.nnz();
-  for (uint64_t i = 0; i < q_off[nq]; ++i)
-    if (comps[i] >= ix.dim) return fail(SGPU_EINVAL, "query component >= dim");
+  {
+    uint32_t max_nnz = 0;
+    const sgpu_status vst = validate_queries(ix.dim, q_off, comps, vals, nq, &max_nnz);
+    if (vst != SGPU_OK) return vst;
+  }
 #ifdef _OPENMP
   const int nt = num_threads ? (int)num_threads : omp_get_max_threads();
 #else
@@ -46,14 +50,33 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
           ival[p] = ix.val(i);
         }
     }
-#pragma omp parallel num_threads(nt)
-    {
-      std::vector<float> acc(ix.n_docs, 0.0f);
-      std::vector<uint8_t> seen(ix.n_docs, 0);
+    // per-thread scratch is sized here, where an allocation failure reaches the enclosing try; inside
+    // the parallel region a failure (growth of the small vectors) is caught per query and flagged
+    struct Thread {
+      std::vector<float> acc;
+      std::vector<uint8_t> seen;
       std::vector<uint32_t> touched;
       std::vector<std::pair<float, uint32_t>> cand;
+    };
+    std::vector<Thread> threads((size_t)nt);
+    for (Thread& t : threads) {
+      t.acc.assign(ix.n_docs, 0.0f);
+      t.seen.assign(ix.n_docs, 0);
+    }
+    std::atomic<int> oom{0};
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+      Thread& me = threads[(size_t)omp_get_thread_num()];
+#else
+      Thread& me = threads[0];
+#endif
+      std::vector<float>& acc = me.acc;
+      std::vector<uint8_t>& seen = me.seen;
+      std::vector<uint32_t>& touched = me.touched;
+      std::vector<std::pair<float, uint32_t>>& cand = me.cand;
 #pragma omp for schedule(dynamic, 1)
-      for (int64_t q = 0; q < (int64_t)nq; ++q) {
+      for (int64_t q = 0; q < (int64_t)nq; ++q) try {
         touched.clear();
         for (uint64_t j = q_off[q]; j < q_off[q + 1]; ++j) {  // ascending component
           const float qv = vals[j];
@@ -94,8 +117,12 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
           acc[d] = 0.0f;
           seen[d] = 0;
         }
+      } catch (const std::bad_alloc&) {
+        oom = 1;
+        out_n[q] = 0;
       }
     }
+    if (oom) return fail(SGPU_ENOMEM, "out of host memory in exact search");
   } catch (const std::bad_alloc&) {
     return fail(SGPU_ENOMEM, "out of host memory in exact search");
   }

@@ -58,6 +58,10 @@ sgpu_status host_index_save(const HostIndex& ix, const char* path);
 sgpu_status host_index_load(const char* path, HostIndex* out);
 sgpu_status host_index_convert(const HostIndex& src, uint32_t value_type, HostIndex* out);
 
+// CSR query batch: q_off[0] == 0 and monotone, components strictly ascending and < dim, no NaN,
+// at most 65535 components per query; *max_nnz = the longest query
+sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t* comps, const float* vals,
+                             uint32_t nq, uint32_t* max_nnz);
 // builder.cpp
 sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim, const uint64_t* offsets,
                              const void* comps, const float* vals, const sgpu_build_config& cfg,

@@ -306,3 +306,17 @@ def test_convert_to_fixed_u8_host_side(tmp_path):
     assert back.desc.value_type == 0
     with pytest.raises(_native.SeismicHipError):
         _native.NativeIndex.build(4, 70000, *random_dataset(93, 50, 70000)).convert(1)   # u16 components only
+
+
+def test_exact_search_validates_its_queries():
+    off, comps, vals = random_dataset(95, 100, 32)
+    ix = _native.NativeIndex.build(2, 32, off, comps, vals, BuildConfig.defaults(n_postings=10))
+    ok = ix.exact_search(np.array([0, 2], np.uint64), np.array([1, 5], np.uint32), np.array([1, 1], np.float32), 5)
+    assert ok[2][0] == 5
+    for q_off, c, v in [([0, 2], [5, 1], [1, 1]),          # not ascending
+                        ([0, 2], [1, 40], [1, 1]),         # component >= dim
+                        ([1, 2], [1, 5], [1, 1]),          # q_off[0] != 0
+                        ([0, 2], [1, 5], [1, np.nan])]:    # NaN weight
+        with pytest.raises(_native.SeismicHipError) as e:
+            ix.exact_search(np.array(q_off, np.uint64), np.array(c, np.uint32), np.array(v, np.float32), 5)
+        assert e.value.status == 1
