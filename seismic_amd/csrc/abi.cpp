@@ -1,8 +1,11 @@
 // abi.cpp — the extern "C" surface declared in include/seismic_hip.h.
+#include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "host_index.hpp"
 
@@ -16,6 +19,7 @@ sgpu_status device_index_clone(const DeviceIndex* src, int device, DeviceIndex**
 void device_index_free(DeviceIndex* d);
 uint64_t device_index_bytes(const DeviceIndex* d);
 Lane* lane_acquire(DeviceIndex* d);
+Lane* lane_try_acquire(DeviceIndex* d);
 void lane_release(DeviceIndex* d, Lane* l);
 Lane* lane_main(DeviceIndex* d);
 sgpu_batch** lane_scratch(Lane* l);
@@ -268,15 +272,69 @@ void sgpu_batch_destroy(sgpu_batch* batch) { batch_free(batch); }
 // One shard of a batch on one replica: borrow a lane (its stream and recycled device batch), H2D of
 // the queries, one kernel pass, D2H of the results. No allocation once the lane's batch has grown to
 // the call's size; calls from different host threads take different lanes and overlap.
+// A large shard is cut into up to four chunks on as many lanes (as many as are free): the host side of
+// chunk i+1 (validation, launch plan, staging of the H2D) runs while the GPU searches chunk i, and
+// the workgroups of chunk i+1 fill the CUs that chunk i's tail leaves idle.
 static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
                                 const float* vals, uint32_t nq, const sgpu_search_params& params,
                                 float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n) {
-  Lane* lane = lane_acquire(d);
-  sgpu_batch** slot = lane_scratch(lane);
-  sgpu_status st = batch_create(d, lane, dim, q_off, comps, vals, nq, params.k, slot);
-  if (st == SGPU_OK) st = batch_run(d, lane, *slot, params, 0, 0, nullptr);
-  if (st == SGPU_OK) st = batch_fetch(d, lane, *slot, params.k, out_scores, out_doc_ids, out_n);
-  lane_release(d, lane);
+  static const uint32_t chunk_min = [] {
+    const char* v = std::getenv("SGPU_CHUNK_MIN");
+    return v && *v ? (uint32_t)std::strtoul(v, nullptr, 10) : 2048u;
+  }();
+  struct Job {
+    Lane* lane;
+    uint32_t q0, q1;
+  };
+  Job jobs[4];
+  uint32_t n_jobs = 1;
+  if (chunk_min && nq >= 2 * chunk_min) n_jobs = std::min<uint32_t>(4, nq / chunk_min);
+  jobs[0].lane = lane_acquire(d);
+  for (uint32_t j = 1; j < n_jobs; ++j) {
+    jobs[j].lane = lane_try_acquire(d);
+    if (!jobs[j].lane) {
+      n_jobs = j;
+      break;
+    }
+  }
+  const uint32_t k = params.k;
+  sgpu_status st = SGPU_OK;
+  std::string msg;
+  uint32_t launched = 0;
+  if (n_jobs > 1) {   // errors name the query by its index in the caller's batch, not in a chunk
+    uint32_t max_nnz = 0;
+    st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz);
+    if (st != SGPU_OK) msg = last_error();
+  }
+  std::vector<uint64_t> off;
+  for (uint32_t j = 0; j < n_jobs && st == SGPU_OK; ++j) {
+    Job& jb = jobs[j];
+    jb.q0 = (uint32_t)((uint64_t)nq * j / n_jobs);
+    jb.q1 = (uint32_t)((uint64_t)nq * (j + 1) / n_jobs);
+    const uint64_t* qo = q_off;
+    if (n_jobs > 1) {
+      off.resize(jb.q1 - jb.q0 + 1);
+      for (uint32_t q = jb.q0; q <= jb.q1; ++q) off[q - jb.q0] = q_off[q] - q_off[jb.q0];
+      qo = off.data();
+    }
+    sgpu_batch** slot = lane_scratch(jb.lane);
+    st = batch_create(d, jb.lane, dim, qo, comps ? comps + q_off[jb.q0] : nullptr, vals ? vals + q_off[jb.q0] : nullptr,
+                      jb.q1 - jb.q0, k, slot);
+    if (st == SGPU_OK) st = batch_run(d, jb.lane, *slot, params, 0, 0, nullptr);
+    if (st == SGPU_OK) ++launched;
+    else msg = last_error();
+  }
+  for (uint32_t j = 0; j < launched; ++j) {   // every launched chunk is waited for, also after an error
+    Job& jb = jobs[j];
+    const sgpu_status fs = batch_fetch(d, jb.lane, *lane_scratch(jb.lane), k, out_scores + (size_t)jb.q0 * k,
+                                       out_doc_ids + (size_t)jb.q0 * k, out_n + jb.q0);
+    if (fs != SGPU_OK && st == SGPU_OK) {
+      st = fs;
+      msg = last_error();
+    }
+  }
+  for (uint32_t j = 0; j < n_jobs; ++j) lane_release(d, jobs[j].lane);
+  if (st != SGPU_OK) last_error() = msg;
   return st;
 }
 

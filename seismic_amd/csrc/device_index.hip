@@ -128,6 +128,18 @@ Lane* lane_acquire(DeviceIndex* d) {
   }
 }
 
+// A free lane, or null: a call that already holds one lane never WAITS for another (two callers each
+// holding some lanes and waiting for more would deadlock).
+Lane* lane_try_acquire(DeviceIndex* d) {
+  std::lock_guard<std::mutex> lk(d->pool_mu);
+  for (Lane& l : d->pool)
+    if (!l.busy) {
+      l.busy = true;
+      return &l;
+    }
+  return nullptr;
+}
+
 void lane_release(DeviceIndex* d, Lane* l) {
   {
     std::lock_guard<std::mutex> lk(d->pool_mu);

@@ -163,3 +163,34 @@ def test_raw_classes_over_the_inner_format(cls, dim, tmp_path):
     assert cls.load(ip).batch_search(qp, 10, 5, 0.8, 0, True) == got
     with pytest.raises(IOError):
         cls.load(str(tmp_path / "missing.idx"))
+
+
+def test_large_batches_are_pipelined_in_chunks(monkeypatch):
+    """sgpu_batch_search cuts a large batch into up to four chunks on as many lanes (host preparation of
+    chunk i+1 overlaps the kernel of chunk i): same rows, input order; errors name the query by its
+    index in the caller's batch; two threads doing it at once share the four lanes without deadlock."""
+    ix, dim = _index(75, 6000, 400)
+    ix.upload(0)
+    q = random_queries(76, 9001, dim, 3, 40)
+    exp = orc.batch_search(ix.desc, *q, 10, 4, 0.9, False)[:3]
+    _same(ix.batch_search(*q, 10, 4, 0.9, False), exp)
+    monkeypatch.setenv("SGPU_CHUNK_MIN", "0")   # (read once per process: this only documents the knob)
+    bad_c = q[1].copy()
+    bad_c[int(q[0][7000])] = dim + 5
+    with pytest.raises(_native.SeismicHipError) as e:
+        ix.batch_search(q[0], bad_c, q[2], 10, 4, 0.9, False)
+    assert "query 7000" in str(e.value)
+    errors = []
+
+    def worker():
+        try:
+            for _ in range(4):
+                _same(ix.batch_search(*q, 10, 4, 0.9, False), exp)
+        except Exception as ex:   # noqa: BLE001
+            errors.append(repr(ex))
+    th = [threading.Thread(target=worker) for _ in range(3)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errors, errors
