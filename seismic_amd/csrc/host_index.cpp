@@ -159,23 +159,17 @@ sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t
   if (q_off[nq] && (!comps || !vals)) return fail(SGPU_EINVAL, "null query arrays");
   // InvertedIndexBase::search asserts sorted components (reference src/inverted_index.rs:172-175)
   // and indexes posting_lists[component] (bounds panic, :193); duplicates are rejected too.
+  // (serial on purpose: half a millisecond per 10 000 queries, where waking an OpenMP team on a
+  // 256-thread host costs tens of milliseconds - this runs inside every search call)
   int bad_kind = 0;
   uint32_t bad_q = 0xffffffffu;
-#pragma omp parallel for schedule(static) if (nq >= 2048)
-  for (int64_t q = 0; q < (int64_t)nq; ++q) {
-    int kind = 0;
-    for (uint64_t i = q_off[q]; i < q_off[q + 1] && !kind; ++i) {
-      if (comps[i] >= dim) kind = 1;
-      else if (i > q_off[q] && comps[i] <= comps[i - 1]) kind = 2;
-      else if (std::isnan(vals[i])) kind = 3;
+  for (uint32_t q = 0; q < nq && !bad_kind; ++q) {
+    for (uint64_t i = q_off[q]; i < q_off[q + 1] && !bad_kind; ++i) {
+      if (comps[i] >= dim) bad_kind = 1;
+      else if (i > q_off[q] && comps[i] <= comps[i - 1]) bad_kind = 2;
+      else if (std::isnan(vals[i])) bad_kind = 3;
     }
-    if (kind) {
-#pragma omp critical
-      if ((uint32_t)q < bad_q) {
-        bad_q = (uint32_t)q;
-        bad_kind = kind;
-      }
-    }
+    if (bad_kind) bad_q = q;
   }
   if (bad_kind == 1) return fail(SGPU_EINVAL, "query %u: component >= dim", bad_q);
   if (bad_kind == 2) return fail(SGPU_EINVAL, "query %u: components must be strictly ascending", bad_q);
