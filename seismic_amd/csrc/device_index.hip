@@ -82,7 +82,7 @@ struct DeviceIndex {
   uint32_t value_type = SGPU_VAL_F16;   // how the records store document values
   float val_scale = 0.0f;
   bool fwd_block_major = false;   // forward store holds a copy of every posting's record, block by block
-  static constexpr int kMainEvents = 64, kPool = 4;
+  static constexpr int kMainEvents = 64, kPool = 6;
   Lane main;
   Lane pool[kPool];
   std::unordered_map<uint64_t, int> occupancy;   // kernel variant + LDS size -> workgroups per CU
@@ -132,6 +132,9 @@ Lane* lane_acquire(DeviceIndex* d) {
 // holding some lanes and waiting for more would deadlock).
 Lane* lane_try_acquire(DeviceIndex* d) {
   std::lock_guard<std::mutex> lk(d->pool_mu);
+  int n_free = 0;
+  for (Lane& l : d->pool) n_free += !l.busy;
+  if (n_free < 2) return nullptr;   // the last free lane is left to a caller that has none
   for (Lane& l : d->pool)
     if (!l.busy) {
       l.busy = true;
