@@ -32,6 +32,9 @@ sgpu_status batch_sync(DeviceIndex* d, sgpu_launch_stats* stats);
 sgpu_status batch_fetch(DeviceIndex* d, Lane* lane, sgpu_batch* b, uint32_t k, float* out_scores, uint64_t* out_ids,
                         uint32_t* out_n);
 sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out);
+sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
+                          const float* vals, uint32_t nq, const sgpu_search_params& sp, sgpu_batch** slot);
+sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_scores, uint64_t* out_ids, uint32_t* out_n);
 sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list, const uint32_t* comps,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
 int device_count();
@@ -317,17 +320,15 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
       for (uint32_t q = jb.q0; q <= jb.q1; ++q) off[q - jb.q0] = q_off[q] - q_off[jb.q0];
       qo = off.data();
     }
-    sgpu_batch** slot = lane_scratch(jb.lane);
-    st = batch_create(d, jb.lane, dim, qo, comps ? comps + q_off[jb.q0] : nullptr, vals ? vals + q_off[jb.q0] : nullptr,
-                      jb.q1 - jb.q0, k, slot);
-    if (st == SGPU_OK) st = batch_run(d, jb.lane, *slot, params, 0, 0, nullptr);
+    st = staged_launch(d, jb.lane, dim, qo, comps ? comps + q_off[jb.q0] : nullptr, vals ? vals + q_off[jb.q0] : nullptr,
+                       jb.q1 - jb.q0, params, lane_scratch(jb.lane));
     if (st == SGPU_OK) ++launched;
     else msg = last_error();
   }
   for (uint32_t j = 0; j < launched; ++j) {   // every launched chunk is waited for, also after an error
     Job& jb = jobs[j];
-    const sgpu_status fs = batch_fetch(d, jb.lane, *lane_scratch(jb.lane), k, out_scores + (size_t)jb.q0 * k,
-                                       out_doc_ids + (size_t)jb.q0 * k, out_n + jb.q0);
+    const sgpu_status fs = staged_finish(d, jb.lane, *lane_scratch(jb.lane), out_scores + (size_t)jb.q0 * k,
+                                         out_doc_ids + (size_t)jb.q0 * k, out_n + jb.q0);
     if (fs != SGPU_OK && st == SGPU_OK) {
       st = fs;
       msg = last_error();

@@ -517,6 +517,14 @@ struct sgpu_batch {
   uint64_t* out_ids = nullptr;
   uint32_t* out_n = nullptr;
   uint32_t* out_stats = nullptr;   // nq x STATS_WORDS work counters of the last pass
+  // Staged batches (the recycled batch of a pool lane, behind sgpu_search / sgpu_batch_search): every
+  // device array above is a slice of ONE device arena mirrored by ONE pinned host buffer, so a call is
+  // one H2D (work counter, queries, launch order), the kernel, one D2H (counts, scores, ids).
+  bool staged = false;
+  uint8_t* arena_dev = nullptr;
+  uint8_t* arena_host = nullptr;
+  size_t arena_cap = 0, in_bytes = 0, out_off = 0, out_bytes = 0;
+  uint32_t* queue_dev = nullptr;
 };
 
 namespace sgpu {
@@ -530,6 +538,12 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
 void batch_free(sgpu_batch* b) {
   if (!b) return;
   if (b->device >= 0) (void)hipSetDevice(b->device);
+  if (b->staged) {
+    (void)hipFree(b->arena_dev);
+    (void)hipHostFree(b->arena_host);
+    delete b;
+    return;
+  }
   (void)hipFree(b->q_off);
   (void)hipFree(b->q_comp);
   (void)hipFree(b->q_val);
@@ -622,22 +636,18 @@ const DeviceIndex* batch_replica(const sgpu_batch* b) { return b ? b->owner : nu
 // Which lists each query will walk (the device applies the same rule: query_cut heaviest
 // components by f32::total_cmp, ties by ascending component), hence how many block dots it
 // needs in LDS, and an a-priori cost (postings of those lists) to start long queries first.
-static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, const sgpu_batch_plan** out) {
-  for (const auto& pl : b->plans)
-    if (pl.query_cut == query_cut) {
-      *out = &pl;
-      return SGPU_OK;
-    }
+static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const uint32_t* h_comp, const float* h_val,
+                             uint32_t nq, uint32_t query_cut, sgpu_batch_plan* out) {
   try {
-    sgpu_batch_plan pl;
+    sgpu_batch_plan& pl = *out;
     pl.query_cut = query_cut;
-    std::vector<std::pair<uint64_t, uint32_t>> cost(b->nq);
+    std::vector<std::pair<uint64_t, uint32_t>> cost(nq);
     uint32_t max_nb = 0, dots_cap = 1, max_list_nb = 1;
     {   // serial on purpose (about a millisecond per 10 000 queries; an OpenMP team costs more to wake)
       std::vector<std::pair<int32_t, uint32_t>> kv;
-      for (int64_t q = 0; q < (int64_t)b->nq; ++q) {
+      for (int64_t q = 0; q < (int64_t)nq; ++q) {
         kv.clear();
-        for (uint64_t i = b->h_off[q]; i < b->h_off[q + 1]; ++i) kv.emplace_back(total_key(b->h_val[i]), b->h_comp[i]);
+        for (uint64_t i = h_off[q]; i < h_off[q + 1]; ++i) kv.emplace_back(total_key(h_val[i]), h_comp[i]);
         const size_t nl = std::min<size_t>(query_cut, kv.size());
         std::partial_sort(kv.begin(), kv.begin() + (long)nl, kv.end(),
                           [](const std::pair<int32_t, uint32_t>& a, const std::pair<int32_t, uint32_t>& c) {
@@ -661,8 +671,25 @@ static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, c
     pl.max_list_nb = max_list_nb;
     std::stable_sort(cost.begin(), cost.end(),
                      [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) { return a.first > c.first; });
-    pl.order.resize(b->nq);
-    for (uint32_t i = 0; i < b->nq; ++i) pl.order[i] = cost[i].second;
+    pl.order.resize(nq);
+    for (uint32_t i = 0; i < nq; ++i) pl.order[i] = cost[i].second;
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of host memory planning a query batch");
+  }
+  return SGPU_OK;
+}
+
+static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, const sgpu_batch_plan** out) {
+  for (const auto& pl : b->plans)
+    if (pl.query_cut == query_cut) {
+      *out = &pl;
+      return SGPU_OK;
+    }
+  if (b->staged) return fail(SGPU_EINVAL, "a staged batch is planned when it is staged");
+  sgpu_batch_plan pl;
+  sgpu_status st = make_plan(d, b->h_off.data(), b->h_comp.data(), b->h_val.data(), b->nq, query_cut, &pl);
+  if (st != SGPU_OK) return st;
+  try {
     b->plans.push_back(std::move(pl));
   } catch (const std::bad_alloc&) {
     return fail(SGPU_ENOMEM, "out of host memory planning a query batch");
@@ -835,7 +862,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     }
     a->qb.q_order = b->q_order;
   }
-  a->qb.out_stats = mode != MODE_DOTS ? b->out_stats : nullptr;
+  a->qb.out_stats = mode != MODE_DOTS ? b->out_stats : nullptr;   // (null for staged batches: no work counters)
   // occupancy of this kernel variant at this LDS size: queried once, then remembered
   int per_cu = 0;
   {
@@ -874,7 +901,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     }
     a->bitmaps = lane->bitmaps;
   }
-  a->queue = lane->queue;
+  a->queue = b->staged ? b->queue_dev : lane->queue;
   return SGPU_OK;
 }
 
@@ -980,6 +1007,112 @@ sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out) {
   HIP_TRY(hipSetDevice(d->device));
   HIP_TRY(hipStreamSynchronize(d->main.stream));
   if (b->nq) HIP_TRY(hipMemcpy(out, b->out_stats, (size_t)b->nq * STATS_WORDS * 4, hipMemcpyDeviceToHost));
+  return SGPU_OK;
+}
+
+// ---- staged batches: the lean path behind sgpu_search / sgpu_batch_search ----------------------
+static inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// Validates, plans, stages and launches one search of `nq` queries on `lane`: one H2D, the kernel, one
+// D2H, all enqueued; staged_finish waits and hands the rows out. *slot is the lane's recycled batch.
+sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
+                          const float* vals, uint32_t nq, const sgpu_search_params& sp, sgpu_batch** slot) {
+  if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
+  if (sp.k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
+  if (sp.k > 1024) return fail(SGPU_ELIMIT, "k = %u exceeds the heap limit of 1024", sp.k);
+  uint32_t max_nnz = 0;
+  sgpu_status st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz);
+  if (st != SGPU_OK) return st;
+  HIP_TRY(hipSetDevice(d->device));
+  const uint64_t nnz = q_off[nq];
+  const uint32_t k = sp.k;
+  // arena: [work counter 16 B | q_off | q_comp | q_val | order]  ->  [out_n | out_scores | out_ids]
+  const size_t o_off = 16, o_comp = o_off + al16((size_t)(nq + 1) * 4), o_val = o_comp + al16(nnz * 4),
+               o_order = o_val + al16(nnz * 4), in_bytes = o_order + al16((size_t)nq * 4);
+  const size_t r_n = in_bytes, r_sc = r_n + al16((size_t)nq * 4), r_id = r_sc + al16((size_t)nq * k * 4),
+               total = r_id + al16((size_t)nq * k * 8);
+  sgpu_batch* b = *slot;
+  if (b && (!b->staged || b->owner != d || b->arena_cap < total)) {
+    HIP_TRY(hipStreamSynchronize(lane->stream));
+    batch_free(b);
+    b = nullptr;
+    *slot = nullptr;
+  }
+  if (!b) {
+    b = new (std::nothrow) sgpu_batch();
+    if (!b) return fail(SGPU_ENOMEM, "out of host memory");
+    b->staged = true;
+    b->device = d->device;
+    b->owner = d;
+    b->arena_cap = std::max<size_t>(total + total / 4, 1 << 16);   // some room: a stream of similar calls settles
+    if (hipMalloc((void**)&b->arena_dev, b->arena_cap) != hipSuccess ||
+        hipHostMalloc((void**)&b->arena_host, b->arena_cap, hipHostMallocDefault) != hipSuccess) {
+      batch_free(b);
+      return fail(SGPU_ENOMEM, "allocation of a %zu-byte staging arena failed", b->arena_cap);
+    }
+    *slot = b;
+  }
+  b->nq = nq;
+  b->k_max = k;
+  b->max_nnz = max_nnz;
+  b->in_bytes = in_bytes;
+  b->out_off = r_n;
+  b->out_bytes = total - r_n;
+  if (nq == 0) return SGPU_OK;
+  const uint32_t qn = std::max<uint32_t>(4, (max_nnz + 3u) & ~3u);
+  const uint32_t cut = std::min<uint32_t>(sp.query_cut, qn);
+  try {
+    b->plans.clear();
+    b->plans.emplace_back();
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of host memory planning a query batch");
+  }
+  st = make_plan(d, q_off, comps, vals, nq, cut, &b->plans.back());
+  if (st != SGPU_OK) return st;
+  uint8_t* hs = b->arena_host;
+  std::memset(hs, 0, 16);
+  uint32_t* h32 = (uint32_t*)(hs + o_off);
+  for (uint32_t q = 0; q <= nq; ++q) h32[q] = (uint32_t)q_off[q];
+  if (nnz) {
+    std::memcpy(hs + o_comp, comps, nnz * 4);
+    std::memcpy(hs + o_val, vals, nnz * 4);
+  }
+  std::memcpy(hs + o_order, b->plans.back().order.data(), (size_t)nq * 4);
+  b->queue_dev = (uint32_t*)b->arena_dev;
+  b->q_off = (uint32_t*)(b->arena_dev + o_off);
+  b->q_comp = (uint32_t*)(b->arena_dev + o_comp);
+  b->q_val = (float*)(b->arena_dev + o_val);
+  b->q_order = (uint32_t*)(b->arena_dev + o_order);
+  b->order_cut = cut;
+  b->out_n = (uint32_t*)(b->arena_dev + r_n);
+  b->out_scores = (float*)(b->arena_dev + r_sc);
+  b->out_ids = (uint64_t*)(b->arena_dev + r_id);
+  b->out_stats = nullptr;
+  HIP_TRY(hipMemcpyAsync(b->arena_dev, hs, in_bytes, hipMemcpyHostToDevice, lane->stream));
+  {
+    std::lock_guard<std::mutex> lock(d->mu);   // the occupancy cache is shared by the lanes
+    LaunchArgs a{};
+    st = configure(d, lane, b, sp, MODE_SEARCH, &a);
+    if (st != SGPU_OK) {
+      (void)hipStreamSynchronize(lane->stream);
+      return st;
+    }
+    HIP_TRY(launch_search(a));
+  }
+  HIP_TRY(hipMemcpyAsync(hs + r_n, b->arena_dev + r_n, b->out_bytes, hipMemcpyDeviceToHost, lane->stream));
+  return SGPU_OK;
+}
+
+// Waits for the lane's staged search and copies the rows out (nq x k slabs, row q padded past out_n[q]).
+sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_scores, uint64_t* out_ids, uint32_t* out_n) {
+  HIP_TRY(hipSetDevice(d->device));
+  HIP_TRY(hipStreamSynchronize(lane->stream));
+  if (!b || b->nq == 0) return SGPU_OK;
+  const size_t nq = b->nq, k = b->k_max;
+  const uint8_t* r = b->arena_host + b->out_off;
+  std::memcpy(out_n, r, nq * 4);
+  std::memcpy(out_scores, r + al16(nq * 4), nq * k * 4);
+  std::memcpy(out_ids, r + al16(nq * 4) + al16(nq * k * 4), nq * k * 8);
   return SGPU_OK;
 }
 
