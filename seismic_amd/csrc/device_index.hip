@@ -280,8 +280,9 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     //     line, its records follow each other). A block's documents are then one contiguous run of
     //     HBM: whole lines are useful and consecutive lines share DRAM pages, where document-major
     //     records are ~4 scattered lines each with the first and last one half used. It costs
-    //     n_postings / n_docs (5-6x on MS MARCO shapes: 23 GB; 195 GB on the 5M x 200K shape) of the
-    //     288 GB; it is used whenever index + copies stay below 85% of the free HBM.
+    //     n_postings / n_docs (5-6x on MS MARCO shapes: 23 GB) of the 288 GB; used up to 96 GB of copies
+    //     (the 5M x 200K-vocabulary shape would take 195 GB and, not being bound by line fetches with
+    //     its u32 components and packed lookup, gains nothing from them: measured 63.6% either way).
     //   document-major: one record per document, postings point into it (large indexes).
     const uint64_t doc_units = rec_off16[h.n_docs];
     std::vector<uint64_t> pref(h.n_postings());
@@ -306,7 +307,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       const char* env_layout = std::getenv("SGPU_FWD_LAYOUT");   // "block" | "doc"; default: block when it fits
       const uint64_t need = (doc_units + blk_units) * 16 + h.n_postings() * 24 + h.n_entries() * 8;
       bool block_major = blk_units > 0 && (doc_units + 8 + blk_units) < (1ull << 48) &&
-                         need < (uint64_t)(0.85 * (double)free_b);
+                         need < (uint64_t)(0.6 * (double)free_b) && blk_units * 16 <= (96ull << 30);
       if (env_layout && std::strcmp(env_layout, "doc") == 0) block_major = false;
       if (env_layout && std::strcmp(env_layout, "block") == 0 && blk_units > 0) block_major = true;
       const uint64_t blk_base = (doc_units + 7) & ~7ull;
