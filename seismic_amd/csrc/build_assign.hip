@@ -23,7 +23,7 @@
 #include <numeric>
 #include <vector>
 
-#include "common.hpp"
+#include "build_device.hpp"
 
 namespace sgpu {
 

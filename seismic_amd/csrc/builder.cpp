@@ -25,17 +25,10 @@
 #include <omp.h>
 #endif
 
+#include "build_device.hpp"
 #include "host_index.hpp"
 
 namespace sgpu {
-// build_assign.hip: the clustering step on a HIP device
-uint32_t device_assign_max_centroids();
-sgpu_status device_assign_clusters(int device, uint32_t comp_width, uint64_t n_docs, uint64_t dim, uint64_t nnz,
-                                   const uint64_t* doc_off, const void* doc_comp, const uint16_t* doc_val,
-                                   const void* top, uint32_t doc_cut, uint32_t min_cluster_size,
-                                   const uint64_t* lp_off, const uint32_t* post, const uint64_t* lc_off,
-                                   const uint32_t* cent, const uint8_t* eligible, uint64_t inv_cap,
-                                   uint32_t* cid_out);
 namespace {
 
 struct Docs {
@@ -233,12 +226,11 @@ void cluster_list_cpu(const Docs& d, const std::vector<uint32_t>& postings_by_va
   for (uint32_t c : s.touched_comps) s.comp_cnt[c] = 0;
 }
 
-// Blocks from the final (centroid doc, doc) pairs, then the per-block summaries and the list's summary CSR.
-void finish_list(const Docs& d, std::vector<std::pair<uint32_t, uint32_t>>& fin, const sgpu_build_config& cfg, Scratch& s,
-                 ListOut& o) {
+// Blocks from the final (centroid doc, doc) pairs (src/posting_list.rs:262-300): postings reordered
+// cluster by cluster, clusters in ascending centroid document id.
+void form_blocks(std::vector<std::pair<uint32_t, uint32_t>>& fin, ListOut& o) {
   const size_t len = fin.size();
   std::sort(fin.begin(), fin.end());
-
   o.post.resize(len);
   o.block_off.assign(1, 0);
   for (size_t i = 0; i < fin.size();) {
@@ -248,66 +240,75 @@ void finish_list(const Docs& d, std::vector<std::pair<uint32_t, uint32_t>>& fin,
     o.block_off.push_back((uint32_t)j);
     i = j;
   }
-  const size_t nb = o.block_off.size() - 1;
+}
 
-  // ---- energy_preserving_summary per block + quantisation ----
-  struct Ent {
-    uint32_t comp;
-    uint16_t bid;
-    uint8_t code;
-  };
-  std::vector<Ent> ents;
-  o.mins.resize(nb);
-  o.quants.resize(nb);
+struct SummaryTmp {
   std::vector<std::pair<float, uint32_t>> cv;  // (value, comp)
   std::vector<float> kv;
-  std::vector<uint8_t> kc;
-  for (size_t b = 0; b < nb; ++b) {
-    s.scomps.clear();
-    for (uint32_t t = o.block_off[b]; t < o.block_off[b + 1]; ++t) {
-      const uint32_t doc = o.post[t];
-      for (uint64_t i = d.off[doc]; i < d.off[doc + 1]; ++i) {
-        const uint32_t c = d.comps[i];
-        const float v = f16_to_f32(d.vals[i]);
-        if (!s.has[c]) {
-          s.has[c] = 1;
-          s.maxv[c] = v;
-          s.scomps.push_back(c);
-        } else if (s.maxv[c] < v) {
-          s.maxv[c] = v;
-        }
+};
+
+// energy_preserving_summary of one block + its u8 quantisation (src/posting_list.rs:329-368,
+// src/utils.rs:68-90): kept components ascending in `comps`, their codes in `codes`.
+void summarize_block_cpu(const Docs& d, const uint32_t* docs, uint32_t n_docs_b, float summary_energy, Scratch& s,
+                         SummaryTmp& t, std::vector<uint32_t>& comps, std::vector<uint8_t>& codes, float* mn, float* qt) {
+  s.scomps.clear();
+  for (uint32_t x = 0; x < n_docs_b; ++x) {
+    const uint32_t doc = docs[x];
+    for (uint64_t i = d.off[doc]; i < d.off[doc + 1]; ++i) {
+      const uint32_t c = d.comps[i];
+      const float v = f16_to_f32(d.vals[i]);
+      if (!s.has[c]) {
+        s.has[c] = 1;
+        s.maxv[c] = v;
+        s.scomps.push_back(c);
+      } else if (s.maxv[c] < v) {
+        s.maxv[c] = v;
       }
     }
-    cv.clear();
-    for (uint32_t c : s.scomps) {
-      cv.emplace_back(s.maxv[c], c);
-      s.has[c] = 0;
-    }
-    std::sort(cv.begin(), cv.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) {
-      const int32_t ka = total_key(a.first), kb = total_key(b.first);
-      if (ka != kb) return ka > kb;
-      return a.second < b.second;
-    });
-    float tot = 0.0f;
-    for (auto& x : cv) tot = tot + x.first;
-    const float until = tot * cfg.summary_energy;
-    float acc = 0.0f;
-    size_t keep = 0;
-    for (; keep < cv.size();) {  // take_while_inclusive
-      acc = acc + cv[keep].first;
-      ++keep;
-      if (!(acc < until)) break;
-    }
-    cv.resize(keep);
-    std::sort(cv.begin(), cv.end(),
-              [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.second < b.second; });
-    kv.resize(keep);
-    kc.resize(keep);
-    for (size_t i = 0; i < keep; ++i) kv[i] = cv[i].first;
-    quantize_block(kv.data(), keep, &o.mins[b], &o.quants[b], kc.data());
-    for (size_t i = 0; i < keep; ++i) ents.push_back({cv[i].second, (uint16_t)b, kc[i]});
   }
-  // per-list summary CSR by component (src/quantized_summary.rs:303-357)
+  auto& cv = t.cv;
+  cv.clear();
+  for (uint32_t c : s.scomps) {
+    cv.emplace_back(s.maxv[c], c);
+    s.has[c] = 0;
+  }
+  std::sort(cv.begin(), cv.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) {
+    const int32_t ka = total_key(a.first), kb = total_key(b.first);
+    if (ka != kb) return ka > kb;
+    return a.second < b.second;
+  });
+  float tot = 0.0f;
+  for (auto& x : cv) tot = tot + x.first;
+  const float until = tot * summary_energy;
+  float acc = 0.0f;
+  size_t keep = 0;
+  for (; keep < cv.size();) {  // take_while_inclusive
+    acc = acc + cv[keep].first;
+    ++keep;
+    if (!(acc < until)) break;
+  }
+  cv.resize(keep);
+  std::sort(cv.begin(), cv.end(),
+            [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.second < b.second; });
+  t.kv.resize(keep);
+  comps.resize(keep);
+  codes.resize(keep);
+  for (size_t i = 0; i < keep; ++i) {
+    t.kv[i] = cv[i].first;
+    comps[i] = cv[i].second;
+  }
+  quantize_block(t.kv.data(), keep, mn, qt, codes.data());
+}
+
+struct Ent {
+  uint32_t comp;
+  uint16_t bid;
+  uint8_t code;
+};
+
+// per-list summary CSR by component (src/quantized_summary.rs:303-357) from the blocks' kept entries
+// (block after block, components ascending inside a block)
+void assemble_csr(std::vector<Ent>& ents, ListOut& o) {
   std::stable_sort(ents.begin(), ents.end(), [](const Ent& a, const Ent& b) { return a.comp < b.comp; });
   o.row_comp.clear();
   o.row_ptr.assign(1, 0);
@@ -539,7 +540,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
     }
 
     lap("device clustering");
-    // ---- phase 3: blocks and summaries (and the clustering of the lists that stayed on the host) ----
+    // ---- phase 3a: blocks (and the clustering of the lists that stayed on the host) ----
     std::vector<ListOut> outs(dim);
 #pragma omp parallel num_threads(nt)
     {
@@ -565,7 +566,79 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
           cd.assign(cp, cp + (lc_off[(size_t)c + 1] - lc_off[(size_t)c]));
           cluster_list_cpu(d, pl, cd, cfg, top, s, fin);
         }
-        finish_list(d, fin, cfg, s, outs[(size_t)c]);
+        form_blocks(fin, outs[(size_t)c]);
+      } catch (const std::bad_alloc&) {
+        oom = 1;
+      }
+    }
+    if (oom) return fail(SGPU_ENOMEM, "out of host memory building the index");
+    lap("clustering (host) + blocks");
+
+    // ---- phase 3b: per-block summaries on the device (build_summaries.hip) for the blocks it can take ----
+    // global block numbering and the reordered postings, list after list
+    std::vector<uint64_t> gb_start(dim + 1, 0);
+    for (uint64_t c = 0; c < dim; ++c) gb_start[c + 1] = gb_start[c] + (outs[c].block_off.empty() ? 0 : outs[c].block_off.size() - 1);
+    const uint64_t n_blocks_all = gb_start[dim];
+    std::vector<uint64_t> sb_post(n_blocks_all + 1, 0);   // postings of block b: post_flat2[sb_post[b] .. sb_post[b+1])
+    std::vector<uint32_t> sb_entries(n_blocks_all, 0);    // document entries of the block
+    std::vector<uint32_t>& post2 = post_flat;             // reused: the postings in block order
+    DeviceSummaries ds;
+    if (on_device) {
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nt)
+      for (int64_t c = 0; c < (int64_t)dim; ++c) {
+        const ListOut& o = outs[(size_t)c];
+        const uint64_t nb = o.block_off.empty() ? 0 : o.block_off.size() - 1;
+        std::copy(o.post.begin(), o.post.end(), post2.begin() + (long)lp_off[(size_t)c]);
+        for (uint64_t b = 0; b < nb; ++b) {
+          uint64_t e = 0;
+          for (uint32_t t = o.block_off[b]; t < o.block_off[b + 1]; ++t) e += d.off[o.post[t] + 1] - d.off[o.post[t]];
+          sb_post[gb_start[(size_t)c] + b + 1] = lp_off[(size_t)c] + o.block_off[b + 1];
+          sb_entries[gb_start[(size_t)c] + b] = (uint32_t)std::min<uint64_t>(e, 0xffffffffu);
+        }
+      }
+      for (uint64_t c = 0; c < dim; ++c)   // first block of a list starts where the list's postings start
+        if (gb_start[c + 1] > gb_start[c]) sb_post[gb_start[c]] = lp_off[c];
+      sgpu_status dst = device_block_summaries((int)cfg.use_device - 1, comp_width, n_docs, nnz, h.fwd_offsets.data(),
+                                               h.fwd_comps.data(), h.fwd_vals.data(), cfg.summary_energy, n_blocks_all,
+                                               sb_post.data(), sb_entries.data(), post2.data(), &ds);
+      if (dst != SGPU_OK) return dst;   // no silent fall back to the host path
+      lap("device summaries");
+    }
+
+    // ---- phase 3c: the remaining summaries on the host, and every list's summary CSR ----
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+      Scratch& s = *scratch[(size_t)omp_get_thread_num()];
+#else
+      Scratch& s = *scratch[0];
+#endif
+      SummaryTmp tmp;
+      std::vector<Ent> ents;
+      std::vector<uint32_t> kc;
+      std::vector<uint8_t> kq;
+#pragma omp for schedule(dynamic, 8)
+      for (int64_t c = 0; c < (int64_t)dim; ++c) try {
+        ListOut& o = outs[(size_t)c];
+        const size_t nb = o.block_off.empty() ? 0 : o.block_off.size() - 1;
+        if (nb == 0) continue;
+        o.mins.resize(nb);
+        o.quants.resize(nb);
+        ents.clear();
+        for (size_t b = 0; b < nb; ++b) {
+          const uint64_t gb = gb_start[(size_t)c] + b;
+          if (on_device && ds.done[gb]) {
+            o.mins[b] = ds.mn[gb];
+            o.quants[b] = ds.qt[gb];
+            const uint64_t p0 = ds.start[gb];
+            for (uint32_t i = 0; i < ds.keep[gb]; ++i) ents.push_back({ds.comp[p0 + i], (uint16_t)b, ds.code[p0 + i]});
+          } else {
+            summarize_block_cpu(d, o.post.data() + o.block_off[b], o.block_off[b + 1] - o.block_off[b], cfg.summary_energy, s,
+                                tmp, kc, kq, &o.mins[b], &o.quants[b]);
+            for (size_t i = 0; i < kc.size(); ++i) ents.push_back({kc[i], (uint16_t)b, kq[i]});
+          }
+        }
+        assemble_csr(ents, o);
       } catch (const std::bad_alloc&) {
         oom = 1;
       }
@@ -573,7 +646,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
     if (oom) return fail(SGPU_ENOMEM, "out of host memory building the index");
     top.clear();
     top.shrink_to_fit();
-    lap("clustering (host) + summaries");
+    lap("summaries (host) + CSR");
 
     // ---- concatenate ----
     h.list_block_start.assign(dim + 1, 0);
