@@ -118,10 +118,11 @@ typedef struct sgpu_build_config {
   float max_fraction;         /* 1.5  */
   uint32_t doc_cut;           /* 15   */
   uint32_t num_threads;       /* 0 = all host cores */
-  uint32_t use_device;        /* 0 = build on the host cores only; n > 0: the clustering step (the
-                                 k-means assignment of every posting, src/utils.rs:146-237) runs on HIP
-                                 device n - 1. The index is byte-identical either way; a missing or
-                                 failing device is an error, never a silent host build. */
+  uint32_t use_device;        /* 0 = build on the host cores only; n > 0: the clustering (the k-means
+                                 assignment of every posting, src/utils.rs:146-237) and the per-block
+                                 summaries (src/posting_list.rs:329-368) run on HIP device n - 1. The
+                                 index is byte-identical either way; a missing or failing device is an
+                                 error, never a silent host build. */
   uint32_t reserved;
 } sgpu_build_config;
 
