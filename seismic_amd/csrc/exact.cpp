@@ -59,11 +59,24 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
       std::vector<std::pair<float, uint32_t>> cand;
     };
     std::vector<Thread> threads((size_t)nt);
-    for (Thread& t : threads) {
-      t.acc.assign(ix.n_docs, 0.0f);
-      t.seen.assign(ix.n_docs, 0);
-    }
     std::atomic<int> oom{0};
+    // (sized by the threads themselves - 44 MB each at 8.8M documents - in a region without a
+    // worksharing construct, so a failure is caught where it happens)
+#pragma omp parallel num_threads(nt)
+    {
+#ifdef _OPENMP
+      Thread& me = threads[(size_t)omp_get_thread_num()];
+#else
+      Thread& me = threads[0];
+#endif
+      try {
+        me.acc.assign(ix.n_docs, 0.0f);
+        me.seen.assign(ix.n_docs, 0);
+      } catch (const std::bad_alloc&) {
+        oom = 1;
+      }
+    }
+    if (oom) return fail(SGPU_ENOMEM, "out of host memory in exact search");
 #pragma omp parallel num_threads(nt)
     {
 #ifdef _OPENMP
@@ -75,8 +88,10 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
       std::vector<uint8_t>& seen = me.seen;
       std::vector<uint32_t>& touched = me.touched;
       std::vector<std::pair<float, uint32_t>>& cand = me.cand;
+      const bool ready = acc.size() == ix.n_docs && seen.size() == ix.n_docs;   // (a smaller team than asked for leaves slots unused)
 #pragma omp for schedule(dynamic, 1)
       for (int64_t q = 0; q < (int64_t)nq; ++q) try {
+        if (!ready) throw std::bad_alloc();
         touched.clear();
         for (uint64_t j = q_off[q]; j < q_off[q + 1]; ++j) {  // ascending component
           const float qv = vals[j];

@@ -7,7 +7,7 @@ for f in sk_*.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --offload-device-only --no-gpu-bundle-output -c "$f" -o "$TMP/${f%.hip}.co" -Wno-unknown-pragmas -Wno-unused-parameter &
 done
 wait
-printf "%-62s %5s %5s %6s %6s %8s\n" "kernel<component, threads, heap regs, lookup, counted>" vgpr sgpr vspill sspill scratch
+printf "%-62s %5s %5s %6s %6s %8s\n" "kernel<component, threads, heap regs, lookup, counted, value type>" vgpr sgpr vspill sspill scratch
 for f in "$TMP"/*.co; do
   /opt/rocm/lib/llvm/bin/llvm-readelf --notes "$f" | awk '
     /\.name:/ {name=$2}
