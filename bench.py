@@ -300,9 +300,11 @@ def main():
         "dtype": "f32",
         "data": "synthetic" if not args.documents else "file",
         "config": {
-            "workload": ("MSMARCO-passage SPLADE-v3 shape (synthetic): %d docs, %d vocab, ~120 nnz/doc, best_configs params, "
+            "workload": ("%s: %d docs, %d vocab, ~%d nnz/doc, best_configs params, "
                          "k=%d, %d-query batch per step%s, %d distinct batches, %dxMI355X"
-                         % (int(d.n_docs), int(d.dim), args.k, args.queries,
+                         % ("MSMARCO-passage SPLADE-v3 shape (synthetic)" if not args.documents
+                            else "documents %s" % os.path.basename(args.documents),
+                            int(d.n_docs), int(d.dim), int(d.nnz) // max(int(d.n_docs), 1), args.k, args.queries,
                             (" sharded over %d GPUs" % world) if (world > 1 and scaling == "strong") else
                             (" per GPU" if world > 1 else ""), n_batches, world)),
             "workload_key": key,

@@ -50,3 +50,41 @@ def test_two_ranks_weak_scaling(tmp_path):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["config"]["launch"]["queries_per_launch"] == 1501
     assert out["value"] > 0
+
+
+def test_bench_on_files_in_the_reference_formats(tmp_path):
+    """bench.py --documents/--queries-file/--groundtruth/--results-tsv: Seismic's inner binary format in,
+    perf_inverted_index's TSV out, accuracy as scripts/run_experiments.py:287-309 computes it. The ground
+    truth here is the exact top-10 (sgpu_exact_search) written in the same TSV layout."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import seismic_amd
+    from seismic_amd import _native
+    from seismic_amd._abi import BuildConfig
+    from seismic_amd.index import read_results_tsv
+    dim = 30_000
+    docs = _native.synth(60_000, dim, 42, 0)
+    q = _native.synth(300, dim, 43, 1, docs)
+    dp, qp, gp, rp = (str(tmp_path / n) for n in ("documents.bin", "queries.bin", "groundtruth.tsv", "results.tsv"))
+    seismic_amd.write_inner_format(dp, *docs)
+    seismic_amd.write_inner_format(qp, *q)
+    ix = _native.NativeIndex.build(2, dim, *docs, BuildConfig.defaults(n_postings=300, centroid_fraction=0.2,
+                                                                        summary_energy=0.5, max_fraction=6.0))
+    es, ei, en = ix.exact_search(*q, 10)
+    _native.write_results_tsv(gp, es, ei, en)
+    env = dict(os.environ, SGPU_INDEX_CACHE=str(tmp_path))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--documents", dp, "--queries-file", qp, "--groundtruth", gp,
+           "--results-tsv", rp, "--n-postings", "300", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-latency", "--no-e2e"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["data"] == "file" and out["config"]["launch"]["queries_per_launch"] == 300
+    res, gt = read_results_tsv(rp), read_results_tsv(gp)
+    assert len(res) == 300 and all(len(v) == 10 for v in res.values())
+    hit = sum(len(set(res[i]) & set(gt[i])) for i in range(300)) / 3000.0
+    assert out["accuracy_vs_groundtruth"] == pytest.approx(hit) and hit > 0.8
+    assert out["recall_at_k"] == pytest.approx(hit)        # the same quantity, computed by bench against exact search
+    ix.upload(0)                                            # the TSV holds exactly what the API returns
+    gs, gi, gn = ix.batch_search(*q, 10, 4, 1.0, False)
+    assert [int(x) for x in gi[7, :gn[7]]] == res[7]
