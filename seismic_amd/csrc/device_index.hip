@@ -21,12 +21,14 @@ hipError_t run_u16_dense(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_packed(const LaunchArgs& a, int* occupancy);
 hipError_t run_u32_split(const LaunchArgs& a, int* occupancy);
 hipError_t run_u32_packed(const LaunchArgs& a, int* occupancy);
+hipError_t run_u32_hash(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_dense_u8(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_packed_u8(const LaunchArgs& a, int* occupancy);
 
 static hipError_t run_any(const LaunchArgs& a, int* occ) {
   if (a.value_type == SGPU_VAL_FIXEDU8) return a.lookup == LK_DENSE ? run_u16_dense_u8(a, occ) : run_u16_packed_u8(a, occ);
   if (a.comp_width == 2) return a.lookup == LK_DENSE ? run_u16_dense(a, occ) : run_u16_packed(a, occ);
+  if (a.lookup == LK_HASH) return run_u32_hash(a, occ);
   return a.lookup == LK_SPLIT ? run_u32_split(a, occ) : run_u32_packed(a, occ);
 }
 hipError_t occupancy_search(const LaunchArgs& a, int* blocks_per_cu) { return run_any(a, blocks_per_cu); }
@@ -497,7 +499,9 @@ struct sgpu_batch_plan {   // per (batch, query_cut): LDS need and processing or
   uint32_t dots_cap = 1;    // max over queries of the blocks of the lists it walks
   uint32_t max_nb = 0;      // largest single list walked first (sort buffer sizing)
   uint32_t max_list_nb = 1; // largest single list walked at all (smallest possible dots area)
-  std::vector<uint32_t> order;   // queries, longest expected first
+  std::vector<uint32_t> order;   // queries, longest expected first; followed (second half) by every query's
+                                 // LK_HASH seed: the hash multiplier under which its components do not collide
+  bool hash_ok = true;           // every query of the batch has such a seed
 };
 
 struct sgpu_batch {
@@ -607,8 +611,8 @@ sgpu_status batch_create(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_
     ok = hipMalloc((void**)&b->q_off, (b->cap_nq + 1) * 4) == hipSuccess &&
          hipMalloc((void**)&b->q_comp, b->cap_nnz * 4) == hipSuccess &&
          hipMalloc((void**)&b->q_val, b->cap_nnz * 4) == hipSuccess &&
-         hipMalloc((void**)&b->q_order, b->cap_nq * 4) == hipSuccess &&
-         hipHostMalloc((void**)&b->h_order, b->cap_nq * 4, hipHostMallocDefault) == hipSuccess &&
+         hipMalloc((void**)&b->q_order, b->cap_nq * 8) == hipSuccess &&
+         hipHostMalloc((void**)&b->h_order, b->cap_nq * 8, hipHostMallocDefault) == hipSuccess &&
          hipMalloc((void**)&b->out_scores, std::max<size_t>(slab, 65536) * 4) == hipSuccess &&
          hipMalloc((void**)&b->out_ids, slab * 8) == hipSuccess &&
          hipMalloc((void**)&b->out_n, b->cap_nq * 4) == hipSuccess &&
@@ -673,8 +677,33 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
     pl.max_list_nb = max_list_nb;
     std::stable_sort(cost.begin(), cost.end(),
                      [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) { return a.first > c.first; });
-    pl.order.resize(nq);
+    pl.order.resize(2 * (size_t)nq);
     for (uint32_t i = 0; i < nq; ++i) pl.order[i] = cost[i].second;
+    // LK_HASH seeds (large vocabularies): the first multiplier of the family that sends the query's
+    // components to distinct slots; queries of more than 255 components cannot use the byte table
+    pl.hash_ok = d->comp_width == 4;
+    if (pl.hash_ok) {
+      std::vector<uint32_t> stamp(kHashSlots, 0xffffffffu);
+      uint32_t epoch = 0;
+      for (uint32_t q = 0; q < nq && pl.hash_ok; ++q) {
+        const uint64_t a = h_off[q], e = h_off[q + 1];
+        uint32_t seed = kHashSeeds;
+        if (e - a <= 255)
+          for (uint32_t s = 0; s < kHashSeeds && seed == kHashSeeds; ++s) {
+            const uint32_t mult = hash_mult(s);
+            bool clash = false;
+            for (uint64_t i = a; i < e && !clash; ++i) {
+              uint32_t& slot = stamp[hash_slot(h_comp[i], mult)];
+              clash = slot == epoch;
+              slot = epoch;
+            }
+            ++epoch;
+            if (!clash) seed = s;
+          }
+        if (seed == kHashSeeds) pl.hash_ok = false;
+        pl.order[(size_t)nq + q] = seed & (kHashSeeds - 1);
+      }
+    }
   } catch (const std::bad_alloc&) {
     return fail(SGPU_ENOMEM, "out of host memory planning a query batch");
   }
@@ -805,10 +834,19 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   const bool split = !dense && d->comp_width == 4 && b->max_nnz <= 65535 &&
                      (o + bitmap_bytes + min_uni > budget || env_u32("SGPU_FORCE_SPLIT", 0)) &&
                      !env_u32("SGPU_NO_SPLIT", 0);
-  const uint32_t lookup = dense ? LK_DENSE : (split ? LK_SPLIT : LK_PACKED);
-  const uint64_t lookup_bytes = mode == MODE_DOTS ? 0u : (dense ? dense_bytes : (split ? split_bytes : bitmap_bytes));
+  // large vocabularies, u32 components: a 32 KB hashed byte table (one random LDS read per document
+  // component, then a verified entry) when every query of the batch has a collision-free seed, the
+  // launch order (which carries the seeds) is in use, and it fits at 2 workgroups per CU
+  const uint64_t hash_bytes = (uint64_t)kHashSlots + up(((uint64_t)qn + 1) * 8);
+  const bool hashed = !dense && searching && d->comp_width == 4 && pl && pl->hash_ok && b->max_nnz <= 255 &&
+                      !env_u32("SGPU_NO_LPT", 0) && !env_u32("SGPU_NO_HASH", 0) && d->value_type == SGPU_VAL_F16 &&
+                      (o + hash_bytes + min_uni <= budget || env_u32("SGPU_FORCE_HASH", 0)) &&
+                      !env_u32("SGPU_FORCE_SPLIT", 0);
+  const uint32_t lookup = dense ? LK_DENSE : (hashed ? LK_HASH : (split ? LK_SPLIT : LK_PACKED));
+  const uint64_t lookup_bytes =
+      mode == MODE_DOTS ? 0u : (dense ? dense_bytes : (hashed ? hash_bytes : (split ? split_bytes : bitmap_bytes)));
   L.q_bits = (uint32_t)o;
-  L.q_rank = (uint32_t)(o + (split ? split_bits : lookup_bytes));
+  L.q_rank = (uint32_t)(o + (hashed ? (uint64_t)kHashSlots : (split ? split_bits : lookup_bytes)));
   o += lookup_bytes;
   L.uni = (uint32_t)std::min<uint64_t>(o, 0xffffffffu);
   const uint64_t uni = min_uni;
@@ -854,15 +892,17 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->qb.out_ids = b->out_ids;
   a->qb.out_n = b->out_n;
   a->qb.q_order = nullptr;
+  a->qb.q_seed = nullptr;
   if (pl && !env_u32("SGPU_NO_LPT", 0) && b->nq) {
     // the processing order lives in the batch's own device buffer (no allocation on the path)
     if (b->order_cut != cut) {
       if (b->order_cut != 0xffffffffu) HIP_TRY(hipStreamSynchronize(lane->stream));   // the staging copy may be in flight
-      std::memcpy(b->h_order, pl->order.data(), (size_t)b->nq * 4);
-      HIP_TRY(hipMemcpyAsync(b->q_order, b->h_order, (size_t)b->nq * 4, hipMemcpyHostToDevice, lane->stream));
+      std::memcpy(b->h_order, pl->order.data(), (size_t)b->nq * 8);   // [order | hash seeds]
+      HIP_TRY(hipMemcpyAsync(b->q_order, b->h_order, (size_t)b->nq * 8, hipMemcpyHostToDevice, lane->stream));
       b->order_cut = cut;
     }
     a->qb.q_order = b->q_order;
+    a->qb.q_seed = b->q_order + b->nq;
   }
   a->qb.out_stats = mode != MODE_DOTS ? b->out_stats : nullptr;   // (null for staged batches: no work counters)
   // occupancy of this kernel variant at this LDS size: queried once, then remembered
@@ -1030,7 +1070,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   const uint32_t k = sp.k;
   // arena: [work counter 16 B | q_off | q_comp | q_val | order]  ->  [out_n | out_scores | out_ids]
   const size_t o_off = 16, o_comp = o_off + al16((size_t)(nq + 1) * 4), o_val = o_comp + al16(nnz * 4),
-               o_order = o_val + al16(nnz * 4), in_bytes = o_order + al16((size_t)nq * 4);
+               o_order = o_val + al16(nnz * 4), in_bytes = o_order + al16((size_t)nq * 8);   // [order | hash seeds]
   const size_t r_n = in_bytes, r_sc = r_n + al16((size_t)nq * 4), r_id = r_sc + al16((size_t)nq * k * 4),
                total = r_id + al16((size_t)nq * k * 8);
   sgpu_batch* b = *slot;
@@ -1079,7 +1119,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     std::memcpy(hs + o_comp, comps, nnz * 4);
     std::memcpy(hs + o_val, vals, nnz * 4);
   }
-  std::memcpy(hs + o_order, b->plans.back().order.data(), (size_t)nq * 4);
+  std::memcpy(hs + o_order, b->plans.back().order.data(), (size_t)nq * 8);
   b->queue_dev = (uint32_t*)b->arena_dev;
   b->q_off = (uint32_t*)(b->arena_dev + o_off);
   b->q_comp = (uint32_t*)(b->arena_dev + o_comp);

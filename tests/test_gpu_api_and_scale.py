@@ -87,7 +87,7 @@ def test_kernel_paths_under_forced_small_buffers(env, monkeypatch):
         _same(g, c)
 
 
-@pytest.mark.parametrize("lookup_env", [dict(), dict(SGPU_FORCE_SPLIT="1")])
+@pytest.mark.parametrize("lookup_env", [dict(), dict(SGPU_FORCE_SPLIT="1"), dict(SGPU_NO_HASH="1"), dict(SGPU_FORCE_HASH="1", SGPU_BLOCK="1024")])
 def test_large_vocabulary_u32_k100(lookup_env, monkeypatch):
     for k_, v_ in lookup_env.items():
         monkeypatch.setenv(k_, v_)
@@ -102,6 +102,12 @@ def test_large_vocabulary_u32_k100(lookup_env, monkeypatch):
         g = ix.batch_search(*q, 100, 10, hf, False)
         c = orc.batch_search(ix.desc, *q, 100, 10, hf, False)[:3]
         _same(g, c)
+    # a query of more than 255 components cannot use the hashed byte table: the batch falls back
+    rng = np.random.default_rng(9)
+    big_c = np.sort(rng.choice(dim, 300, replace=False)).astype(np.uint32)
+    big_v = (rng.random(300) + 0.05).astype(np.float32)
+    q2 = (np.concatenate([q[0], [q[0][-1] + 300]]).astype(np.uint64), np.concatenate([q[1], big_c]), np.concatenate([q[2], big_v]))
+    _same(ix.batch_search(*q2, 10, 6, 0.9, True), orc.batch_search(ix.desc, *q2, 10, 6, 0.9, True)[:3])
 
 
 def test_full_size_config_properties():
