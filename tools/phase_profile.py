@@ -27,16 +27,22 @@ ap.add_argument("--query-cut", type=int, default=4)
 ap.add_argument("--heap-factor", type=float, default=1.0)
 ap.add_argument("--first-sorted", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--comp-width", type=int, default=2)
+ap.add_argument("--centroid-fraction", type=float, default=0.2)
+ap.add_argument("--summary-energy", type=float, default=0.5)
+ap.add_argument("--max-fraction", type=float, default=6.0)
+ap.add_argument("--min-cluster-size", type=int, default=2)
 a = ap.parse_args()
 npost = a.n_postings or max(1, 2000 * a.docs // 1000000)
 docs = _native.synth(a.docs, a.dim, 42, 0)
-path = "/tmp/prof_%d_%d_%d.idx" % (a.docs, a.dim, npost)
+path = "/tmp/prof_%d_%d_%d_cw%d_cf%g.idx" % (a.docs, a.dim, npost, a.comp_width, a.centroid_fraction)
 if os.path.exists(path):
     ix = _native.NativeIndex.load(path)
 else:
     t = time.time()
-    ix = _native.NativeIndex.build(2, a.dim, *docs, BuildConfig.defaults(
-        n_postings=npost, centroid_fraction=0.2, summary_energy=0.5, max_fraction=6.0))
+    ix = _native.NativeIndex.build(a.comp_width, a.dim, *docs, BuildConfig.defaults(
+        n_postings=npost, centroid_fraction=a.centroid_fraction, summary_energy=a.summary_energy,
+        max_fraction=a.max_fraction, min_cluster_size=a.min_cluster_size, use_device=1))
     print("build %.1fs" % (time.time() - t))
     ix.save(path)
 ix.upload(0)
