@@ -313,6 +313,18 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       if (env_layout && std::strcmp(env_layout, "doc") == 0) block_major = false;
       if (env_layout && std::strcmp(env_layout, "block") == 0 && blk_units > 0) block_major = true;
       const uint64_t blk_base = (doc_units + 7) & ~7ull;
+      // the store is allocated before the posting refs are laid out: if the block-major region does
+      // not fit after all (memory taken by another process), the index falls back to document-major
+      void* fp = nullptr;
+      size_t fbytes = 0;
+      for (;;) {
+        const uint64_t total_units = block_major ? blk_base + blk_units : doc_units;
+        fbytes = std::max<uint64_t>(total_units * 16, 16);
+        if (hipMalloc(&fp, fbytes) == hipSuccess) break;
+        (void)hipGetLastError();
+        if (!block_major) return bail(fail(SGPU_ENOMEM, "hipMalloc of %zu bytes failed", fbytes));
+        block_major = false;
+      }
       d->fwd_block_major = block_major;
       // Inside a block the records are grouped by the scoring loop's length class (<= 128 elements
       // first, longer ones after; posting order within a class): the kernel scores a round class by
@@ -329,10 +341,6 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
             cur += (((len + 7) & ~7ull) * (cw + vb) + 15) / 16;
           }
       }
-      const uint64_t total_units = block_major ? blk_base + blk_units : doc_units;
-      void* fp = nullptr;
-      const size_t fbytes = std::max<uint64_t>(total_units * 16, 16);
-      if (hipMalloc(&fp, fbytes) != hipSuccess) return bail(fail(SGPU_ENOMEM, "hipMalloc of %zu bytes failed", fbytes));
       d->allocs.push_back(Alloc{fp, fbytes, (size_t)((const char*)&d->view.fwd - (const char*)d)});
       d->bytes += fbytes;
       d->view.fwd = (const uint8_t*)fp;
