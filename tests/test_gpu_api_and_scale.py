@@ -116,7 +116,7 @@ def test_full_size_config_properties():
     dim, n_docs, nq = 30_000, 1_000_000, 1000
     docs = _native.synth(n_docs, dim, 42, 0)
     ix = _native.NativeIndex.build(2, dim, *docs, BuildConfig.defaults(n_postings=2000, centroid_fraction=0.2,
-                                                                        summary_energy=0.5, max_fraction=6.0))
+                                                                        summary_energy=0.5, max_fraction=6.0, use_device=1))
     ix.upload(0)
     q = _native.synth(nq, dim, 43, 1, docs)
     b = _native.DeviceBatch(ix, *q, 10)

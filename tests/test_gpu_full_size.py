@@ -26,7 +26,7 @@ def test_c3_msmarco_shape_full_size_bit_exact():
     dim, n_docs, nq = 30_000, 8_800_000, 1000
     docs = _native.synth(n_docs, dim, 42, 0)
     ix = _native.NativeIndex.build(2, dim, *docs, BuildConfig.defaults(n_postings=2000, centroid_fraction=0.2,
-                                                                        summary_energy=0.5, max_fraction=6.0))
+                                                                        summary_energy=0.5, max_fraction=6.0, use_device=1))
     ix.upload(0)
     big = _native.synth(10 * nq, dim, 43, 1, docs)
     del docs
@@ -52,7 +52,7 @@ def test_c5_large_vocabulary_1m_docs_k100_heap_factor_sweep():
     docs = _native.synth(n_docs, dim, 42, 0)
     ix = _native.NativeIndex.build(4, dim, *docs, BuildConfig.defaults(n_postings=2000, centroid_fraction=0.1,
                                                                         summary_energy=0.4, max_fraction=4.0,
-                                                                        min_cluster_size=10))
+                                                                        min_cluster_size=10, use_device=1))
     ix.upload(0)
     q = _native.synth(nq, dim, 43, 1, docs)
     del docs
@@ -74,7 +74,7 @@ def test_accumulation_order_tolerance_at_full_size(capsys):
     dim, n_docs, nq, k = 30_000, 1_000_000, 1000, 10
     docs = _native.synth(n_docs, dim, 42, 0)
     ix = _native.NativeIndex.build(2, dim, *docs, BuildConfig.defaults(n_postings=2000, centroid_fraction=0.2,
-                                                                        summary_energy=0.5, max_fraction=6.0))
+                                                                        summary_energy=0.5, max_fraction=6.0, use_device=1))
     ix.upload(0)
     q = _native.synth(nq, dim, 43, 1, docs)
     del docs
