@@ -39,11 +39,17 @@ VALUE_LAWS = {
 }
 
 
-@pytest.mark.parametrize("seed", range(14))
+@pytest.mark.parametrize("seed", range(26))
 def test_differential(seed, monkeypatch):
     # small batches default to 1024-thread workgroups; odd seeds force the 512-thread configuration
     if seed % 2:
         monkeypatch.setenv("SGPU_BLOCK", "512")
+    # seeds >= 14 also vary the round-2 machinery: fixed-u8 document values, lists walked one per
+    # group, the document-major forward store, the device-assisted build, two replicas, large k
+    if seed >= 14 and seed % 4 == 1:
+        monkeypatch.setenv("SGPU_DOTS_CAP", "1")
+    if seed >= 14 and seed % 4 == 2:
+        monkeypatch.setenv("SGPU_FWD_LAYOUT", "doc")
     rng = np.random.default_rng(1000 + seed)
     law = ["exp", "ties", "signed"][seed % 3]
     values = VALUE_LAWS[law]
@@ -54,7 +60,15 @@ def test_differential(seed, monkeypatch):
     cfg = dict(n_postings=int(rng.choice([1, 3, 20, 200])), centroid_fraction=float(rng.choice([0.02, 0.1, 0.3, 0.6])),
                summary_energy=float(rng.choice([0.2, 0.5, 0.9, 1.0])), max_fraction=float(rng.choice([1.0, 1.5, 6.0])),
                min_cluster_size=int(rng.integers(0, 6)), doc_cut=int(rng.choice([1, 5, 15])))
-    ix = _native.NativeIndex.build(cw, dim, off, comps, vals, BuildConfig.defaults(**cfg)).upload(0)
+    if seed >= 14 and seed % 3 == 0:
+        cfg["use_device"] = 1
+    ix = _native.NativeIndex.build(cw, dim, off, comps, vals, BuildConfig.defaults(**cfg))
+    if seed >= 14 and cw == 2 and seed % 2 == 0:
+        ix = ix.convert(1)                      # fixed-u8 document values (negative weights quantise to 0)
+    if seed >= 14 and seed % 5 == 0:
+        ix.upload_many([0, 0])                  # two replicas: batches are sharded over them
+    else:
+        ix.upload(0)
     graph = None
     if seed % 2 == 0:
         nknn = int(rng.integers(1, 6))
@@ -64,7 +78,7 @@ def test_differential(seed, monkeypatch):
     try:
         q = _queries(rng, 30, dim, int(rng.choice([5, 40, 120])), values)
         for _ in range(4):
-            k = int(rng.choice([1, 3, 10, 63, 64, 65, 128, 129, 300]))
+            k = int(rng.choice([1, 3, 10, 63, 64, 65, 128, 129, 300] + ([256, 257, 513, 1000] if seed >= 14 else [])))
             qcut = int(rng.integers(1, 13))
             hf = float(rng.choice([0.0, 0.5, 0.8, 1.0, 1.3]))
             srt = bool(rng.integers(0, 2))
