@@ -386,20 +386,6 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     }
     if ((st = dev_copy(d, h.sum_bid.data(), h.sum_bid.size(), &d->view.sum_bid)) != SGPU_OK) return bail(st);
     {
-      // skip index of the summary rows: the component of every 32nd row, list after list
-      std::vector<uint32_t> skip_start(h.dim + 1, 0);
-      for (uint64_t c = 0; c < h.dim; ++c)
-        skip_start[c + 1] = skip_start[c] + (uint32_t)((h.list_row_start[c + 1] - h.list_row_start[c] + 31) / 32);
-      std::vector<uint8_t> skip((size_t)skip_start[h.dim] * cw);
-      for (uint64_t c = 0; c < h.dim; ++c) {
-        const uint64_t r0 = h.list_row_start[c], nr = h.list_row_start[c + 1] - r0;
-        for (uint64_t g = 0; g * 32 < nr; ++g)
-          std::memcpy(skip.data() + ((size_t)skip_start[c] + g) * cw, h.row_comp.data() + (r0 + g * 32) * cw, cw);
-      }
-      if ((st = dev_copy(d, skip.data(), skip.size(), (const uint8_t**)&d->view.row_skip)) != SGPU_OK) return bail(st);
-      if ((st = dev_copy(d, skip_start.data(), skip_start.size(), &d->view.list_skip_start)) != SGPU_OK) return bail(st);
-    }
-    {
       // split point of every summary row at half the list's block ids (rows are ascending in block
       // id, validate_desc): stage 1 gives each half of a list to its own wavefront
       std::vector<uint16_t> mid(h.n_rows());
@@ -792,7 +778,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     L.q_sc = (uint32_t)o;
     o += up(((uint64_t)qn + 1) * 4);
   }
-  L.sel = (uint32_t)o; o += up((7ull * qc + 1) * 4);
+  L.sel = (uint32_t)o; o += up((6ull * qc + 1) * 4);
   if (o + up((uint64_t)qc * qn * 8) > lds_limit)
     return fail(SGPU_ELIMIT, "query_cut %u x %u query components do not fit the row tables in LDS", qc, qn);
   L.rt_start = (uint32_t)o; o += up((uint64_t)qc * qn * 8);

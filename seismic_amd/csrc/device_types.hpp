@@ -19,9 +19,6 @@ struct DevView {
   const void* row_comp;               // n_rows, ascending within a list
   const uint64_t* row_ptr;            // n_rows + 1 (entries can exceed 2^32 on large indexes)
   const uint16_t* sum_bid;            // n_entries: list-local block id, ascending within a row
-  const void* row_skip;               // every 32nd row component of every list (a list's groups are contiguous): the
-                                      //   row search reads this small, cache-resident index first, then one 32-row window
-  const uint32_t* list_skip_start;    // dim + 1
   const uint16_t* row_mid;            // n_rows: entries of the row whose block id is below half the list's blocks
                                       //   (stage 1 splits every list between two wavefronts by block id)
   const float* sum_deq;               // n_entries: code*quant + min of the entry's block, rounded as the
