@@ -161,7 +161,8 @@ sgpu_status sgpu_device_count(int32_t* n);
  * Validates the descriptor, copies it, derives the HBM layout. */
 sgpu_status sgpu_index_create(const sgpu_index_desc* desc, sgpu_index** out);
 /* Replaces: InvertedIndexBase::build (src/inverted_index.rs:603-686) for the
- * Python-exposed configuration. CPU-side, offline. Input = a sparse dataset in
+ * Python-exposed configuration. Offline; on the host cores, or with cfg->use_device the clustering and
+ * the block summaries on a HIP device (same index, byte for byte). Input = a sparse dataset in
  * CSR form, values already f32 (they are rounded to binary16 as
  * from_f32_saturating does, src/json_utils.rs:64). comps are comp_width bytes each. */
 sgpu_status sgpu_index_build(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
