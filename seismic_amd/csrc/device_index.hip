@@ -234,47 +234,18 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     const uint32_t cw = h.comp_width, vb = h.val_bytes();
     d->value_type = h.value_type;
     d->val_scale = h.val_scale;
-    // ---- document records: [npad comps][npad values (f16, or u8 codes)], npad = len rounded up to 8, the
-    // record padded to 16 bytes
-    // A record is moved to the next 128-byte line only if it would otherwise touch more lines than
-    // its size needs: at 16-byte alignment a 480-byte record straddles ~4.75 lines, line-fitted 4
-    // (less HBM traffic per scored document; the run time is the same).
-    std::vector<uint64_t> rec_off16(h.n_docs + 1, 0);
+    // ---- document records (pack_index.cpp): [npad comps][npad values (f16, or u8 codes)], npad = len rounded up
+    // to 8, the record padded to 16 bytes. A record is moved to the next 128-byte line only if it would
+    // otherwise touch more lines than its size needs: at 16-byte alignment a 480-byte record straddles
+    // ~4.75 lines, line-fitted 4.
+    std::vector<uint64_t> rec_off16;
     {
       const char* env_line = std::getenv("SGPU_REC_LINE");
-      const uint64_t line16 = std::max<uint64_t>(16, env_line ? std::strtoul(env_line, nullptr, 10) : 128) / 16;
-      uint64_t cur = 0;
-      for (uint64_t doc = 0; doc < h.n_docs; ++doc) {
-        const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
-        const uint64_t npad = (len + 7) & ~7ull;
-        const uint64_t size16 = (npad * (cw + vb) + 15) / 16;
-        const uint64_t in_line = cur % line16;
-        if (size16 && (in_line + size16 + line16 - 1) / line16 > (size16 + line16 - 1) / line16)
-          cur += line16 - in_line;
-        rec_off16[doc] = cur;
-        cur += size16;
-      }
-      rec_off16[h.n_docs] = cur;
+      pack_record_offsets(h, std::max<uint64_t>(16, env_line ? std::strtoul(env_line, nullptr, 10) : 128) / 16, &rec_off16);
     }
     if (rec_off16[h.n_docs] >= (1ull << 48)) return bail(fail(SGPU_ELIMIT, "forward index exceeds 48-bit record offsets"));
-    std::vector<uint8_t> fwd(std::max<uint64_t>(rec_off16[h.n_docs] * 16, 16), 0);
-#pragma omp parallel for schedule(static)
-    for (int64_t doc = 0; doc < (int64_t)h.n_docs; ++doc) {
-      const uint64_t s0 = h.fwd_offsets[(size_t)doc], len = h.fwd_offsets[(size_t)doc + 1] - s0;
-      const uint64_t npad = (len + 7) & ~7ull;
-      uint8_t* rec = fwd.data() + rec_off16[(size_t)doc] * 16;
-      std::memcpy(rec, h.fwd_comps.data() + s0 * cw, len * cw);
-      if (vb == 2) std::memcpy(rec + npad * cw, h.fwd_vals.data() + s0, len * 2);
-      else std::memcpy(rec + npad * cw, h.fwd_codes.data() + s0, len);
-      // padding components carry the sentinel id `dim` (never a query component) when it is
-      // representable; their values are 0. The dense lookup path relies on it, the bitmap path
-      // tests the length instead.
-      if (cw == 2 && h.dim <= 65535) {
-        for (uint64_t e = len; e < npad; ++e) ((uint16_t*)rec)[e] = (uint16_t)h.dim;
-      } else if (cw == 4) {
-        for (uint64_t e = len; e < npad; ++e) ((uint32_t*)rec)[e] = (uint32_t)h.dim;
-      }
-    }
+    std::vector<uint8_t> fwd;
+    pack_records(h, rec_off16, &fwd);
     // ---- postings: (record offset / 16) << 16 | len, the reference's PackedPostingBlock
     // (src/posting_list.rs:32-60). Forward store layout:
     //   block-major (default when it fits): after the document-major records, every posting gets its
@@ -287,23 +258,12 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     //     its u32 components and packed lookup, gains nothing from them: measured 63.6% either way).
     //   document-major: one record per document, postings point into it (large indexes).
     const uint64_t doc_units = rec_off16[h.n_docs];
-    std::vector<uint64_t> pref(h.n_postings());
+    std::vector<uint64_t> pref;
     uint64_t blk_units = 0;
     {
-      const uint64_t nb = h.n_blocks();
-      std::vector<uint64_t> bsize(nb + 1, 0);
-#pragma omp parallel for schedule(static)
-      for (int64_t b = 0; b < (int64_t)nb; ++b) {
-        uint64_t u = 0;
-        for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
-          const uint32_t doc = h.post_doc[p];
-          const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
-          u += (((len + 7) & ~7ull) * (cw + vb) + 15) / 16;
-        }
-        bsize[(size_t)b + 1] = (u + 7) & ~7ull;   // blocks start on 128-byte lines
-      }
-      for (uint64_t b = 0; b < nb; ++b) bsize[b + 1] += bsize[b];
-      blk_units = bsize[nb];
+      std::vector<uint64_t> bsize;
+      pack_block_sizes(h, &bsize);
+      blk_units = bsize[h.n_blocks()];
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
       const char* env_layout = std::getenv("SGPU_FWD_LAYOUT");   // "block" | "doc"; default: block when it fits
@@ -326,21 +286,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
         block_major = false;
       }
       d->fwd_block_major = block_major;
-      // Inside a block the records are grouped by the scoring loop's length class (<= 128 elements
-      // first, longer ones after; posting order within a class): the kernel scores a round class by
-      // class, so consecutive items of a class are then adjacent records.
-#pragma omp parallel for schedule(static)
-      for (int64_t b = 0; b < (int64_t)nb; ++b) {
-        uint64_t cur = blk_base + bsize[(size_t)b];
-        for (int cls = 0; cls < 2; ++cls)
-          for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
-            const uint32_t doc = h.post_doc[p];
-            const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
-            if ((len > 128) != (cls == 1)) continue;
-            pref[p] = ((block_major ? cur : rec_off16[doc]) << 16) | len;
-            cur += (((len + 7) & ~7ull) * (cw + vb) + 15) / 16;
-          }
-      }
+      pack_post_refs(h, rec_off16, bsize, block_major, blk_base, &pref);
       d->allocs.push_back(Alloc{fp, fbytes, (size_t)((const char*)&d->view.fwd - (const char*)d)});
       d->bytes += fbytes;
       d->view.fwd = (const uint8_t*)fp;
@@ -350,9 +296,8 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     fwd.shrink_to_fit();
     if ((st = dev_copy(d, pref.data(), pref.size(), &d->view.post_ref)) != SGPU_OK) return bail(st);
     {
-      std::vector<uint64_t> dref(h.n_docs);
-      for (uint64_t doc = 0; doc < h.n_docs; ++doc)
-        dref[doc] = (rec_off16[doc] << 16) | (h.fwd_offsets[doc + 1] - h.fwd_offsets[doc]);
+      std::vector<uint64_t> dref;
+      pack_doc_refs(h, rec_off16, &dref);
       if ((st = dev_copy(d, dref.data(), dref.size(), &d->view.doc_ref)) != SGPU_OK) return bail(st);
     }
     pref.clear();
@@ -366,8 +311,8 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       HIP_TRY(hipStreamSynchronize(d->main.stream));
     }
     auto narrow = [](const std::vector<uint64_t>& v) {
-      std::vector<uint32_t> o(v.size());
-      for (size_t i = 0; i < v.size(); ++i) o[i] = (uint32_t)v[i];
+      std::vector<uint32_t> o;
+      pack_narrow(v, &o);
       return o;
     };
     {
@@ -388,31 +333,15 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     {
       // split point of every summary row at half the list's block ids (rows are ascending in block
       // id, validate_desc): stage 1 gives each half of a list to its own wavefront
-      std::vector<uint16_t> mid(h.n_rows());
-      for (uint64_t c = 0; c < h.dim; ++c) {
-        const uint64_t nb = h.list_block_start[c + 1] - h.list_block_start[c];
-        const uint16_t half = (uint16_t)((nb + 1) / 2);
-        for (uint64_t r = h.list_row_start[c]; r < h.list_row_start[c + 1]; ++r) {
-          const uint16_t* b = h.sum_bid.data() + h.row_ptr[r];
-          const uint16_t* e = h.sum_bid.data() + h.row_ptr[r + 1];
-          mid[r] = (uint16_t)(std::lower_bound(b, e, half) - b);
-        }
-      }
+      std::vector<uint16_t> mid;
+      pack_row_mid(h, &mid);
       if ((st = dev_copy(d, mid.data(), mid.size(), &d->view.row_mid)) != SGPU_OK) return bail(st);
     }
     {
       // dequantised summary values: code*quant + min with the reference's two roundings
       // (src/quantized_summary.rs:102-104; this file is compiled with -ffp-contract=off)
-      std::vector<float> deq(h.n_entries());
-      for (uint64_t c = 0; c < h.dim; ++c) {
-        const uint64_t b0 = h.list_block_start[c];
-        for (uint64_t r = h.list_row_start[c]; r < h.list_row_start[c + 1]; ++r)
-          for (uint64_t e = h.row_ptr[r]; e < h.row_ptr[r + 1]; ++e) {
-            const uint64_t blk = b0 + h.sum_bid[e];
-            const volatile float t = (float)h.sum_code[e] * h.blk_quant[blk];
-            deq[e] = t + h.blk_min[blk];
-          }
-      }
+      std::vector<float> deq;
+      pack_sum_deq(h, &deq);
       if ((st = dev_copy(d, deq.data(), deq.size(), &d->view.sum_deq)) != SGPU_OK) return bail(st);
     }
     d->view.knn = nullptr;

@@ -62,6 +62,17 @@ sgpu_status host_index_convert(const HostIndex& src, uint32_t value_type, HostIn
 // at most 65535 components per query; *max_nnz = the longest query
 sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t* comps, const float* vals,
                              uint32_t nq, uint32_t* max_nnz);
+// pack_index.cpp: the host half of the upload (HBM layout of DESIGN.md section 2), on all host cores
+void pack_record_offsets(const HostIndex& h, uint64_t line16, std::vector<uint64_t>* rec_off16);
+void pack_records(const HostIndex& h, const std::vector<uint64_t>& rec_off16, std::vector<uint8_t>* fwd);
+void pack_block_sizes(const HostIndex& h, std::vector<uint64_t>* bsize);
+void pack_post_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, const std::vector<uint64_t>& bsize,
+                    bool block_major, uint64_t blk_base, std::vector<uint64_t>* pref);
+void pack_doc_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, std::vector<uint64_t>* dref);
+void pack_narrow(const std::vector<uint64_t>& v, std::vector<uint32_t>* out);
+void pack_row_mid(const HostIndex& h, std::vector<uint16_t>* mid);
+void pack_sum_deq(const HostIndex& h, std::vector<float>* deq);
+
 // builder.cpp
 sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim, const uint64_t* offsets,
                              const void* comps, const float* vals, const sgpu_build_config& cfg,

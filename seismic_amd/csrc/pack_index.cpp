@@ -1,0 +1,145 @@
+// pack_index.cpp — the host half of sgpu_index_upload: the canonical arrays of a HostIndex packed into
+// the HBM layout of DESIGN.md section 2 (document records, posting refs, summary split points and
+// dequantised summary values). Host code with OpenMP (device_index.hip is compiled by hipcc without it);
+// every output is sized before its parallel loop, so nothing is allocated inside a parallel region.
+#include <algorithm>
+#include <cstring>
+
+#include "host_index.hpp"
+
+namespace sgpu {
+
+// Record offsets in 16-byte units. A record is moved to the next `line16`-unit line only if it would
+// otherwise touch more lines than its size needs (a sequential prefix: cheap, one pass).
+void pack_record_offsets(const HostIndex& h, uint64_t line16, std::vector<uint64_t>* out) {
+  const uint32_t cw = h.comp_width, vb = h.val_bytes();
+  std::vector<uint64_t>& rec_off16 = *out;
+  rec_off16.assign(h.n_docs + 1, 0);
+  uint64_t cur = 0;
+  for (uint64_t doc = 0; doc < h.n_docs; ++doc) {
+    const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
+    const uint64_t npad = (len + 7) & ~7ull;
+    const uint64_t size16 = (npad * (cw + vb) + 15) / 16;
+    const uint64_t in_line = cur % line16;
+    if (size16 && (in_line + size16 + line16 - 1) / line16 > (size16 + line16 - 1) / line16) cur += line16 - in_line;
+    rec_off16[doc] = cur;
+    cur += size16;
+  }
+  rec_off16[h.n_docs] = cur;
+}
+
+// Document records: [npad components][npad values (f16, or u8 codes)], npad = len rounded up to 8, the
+// record padded to 16 bytes. Padding components carry the sentinel id `dim` (never a query component)
+// when it is representable; their values are 0.
+void pack_records(const HostIndex& h, const std::vector<uint64_t>& rec_off16, std::vector<uint8_t>* out) {
+  const uint32_t cw = h.comp_width, vb = h.val_bytes();
+  std::vector<uint8_t>& fwd = *out;
+  fwd.assign(std::max<uint64_t>(rec_off16[h.n_docs] * 16, 16), 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t doc = 0; doc < (int64_t)h.n_docs; ++doc) {
+    const uint64_t s0 = h.fwd_offsets[(size_t)doc], len = h.fwd_offsets[(size_t)doc + 1] - s0;
+    const uint64_t npad = (len + 7) & ~7ull;
+    uint8_t* rec = fwd.data() + rec_off16[(size_t)doc] * 16;
+    std::memcpy(rec, h.fwd_comps.data() + s0 * cw, len * cw);
+    if (vb == 2) std::memcpy(rec + npad * cw, h.fwd_vals.data() + s0, len * 2);
+    else std::memcpy(rec + npad * cw, h.fwd_codes.data() + s0, len);
+    if (cw == 2 && h.dim <= 65535) {
+      for (uint64_t e = len; e < npad; ++e) ((uint16_t*)rec)[e] = (uint16_t)h.dim;
+    } else if (cw == 4) {
+      for (uint64_t e = len; e < npad; ++e) ((uint32_t*)rec)[e] = (uint32_t)h.dim;
+    }
+  }
+}
+
+// Block-major store: bsize[b] = 16-byte units before block b (every block starts on a 128-byte line).
+void pack_block_sizes(const HostIndex& h, std::vector<uint64_t>* out) {
+  const uint32_t cw = h.comp_width, vb = h.val_bytes();
+  const uint64_t nb = h.n_blocks();
+  std::vector<uint64_t>& bsize = *out;
+  bsize.assign(nb + 1, 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < (int64_t)nb; ++b) {
+    uint64_t u = 0;
+    for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
+      const uint32_t doc = h.post_doc[p];
+      const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
+      u += (((len + 7) & ~7ull) * (cw + vb) + 15) / 16;
+    }
+    bsize[(size_t)b + 1] = (u + 7) & ~7ull;
+  }
+  for (uint64_t b = 0; b < nb; ++b) bsize[b + 1] += bsize[b];
+}
+
+// Posting refs (record offset / 16) << 16 | len, the reference's PackedPostingBlock (src/posting_list.rs:32-60).
+// Block-major: inside a block the records are grouped by the scoring loop's length class (<= 128 elements
+// first, longer ones after; posting order within a class), so consecutive items of a class are adjacent records.
+void pack_post_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, const std::vector<uint64_t>& bsize,
+                    bool block_major, uint64_t blk_base, std::vector<uint64_t>* out) {
+  const uint32_t cw = h.comp_width, vb = h.val_bytes();
+  const uint64_t nb = h.n_blocks();
+  std::vector<uint64_t>& pref = *out;
+  pref.assign(h.n_postings(), 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t b = 0; b < (int64_t)nb; ++b) {
+    uint64_t cur = blk_base + bsize[(size_t)b];
+    for (int cls = 0; cls < 2; ++cls)
+      for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
+        const uint32_t doc = h.post_doc[p];
+        const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
+        if ((len > 128) != (cls == 1)) continue;
+        pref[p] = ((block_major ? cur : rec_off16[doc]) << 16) | len;
+        cur += (((len + 7) & ~7ull) * (cw + vb) + 15) / 16;
+      }
+  }
+}
+
+void pack_doc_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, std::vector<uint64_t>* out) {
+  std::vector<uint64_t>& dref = *out;
+  dref.assign(h.n_docs, 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t doc = 0; doc < (int64_t)h.n_docs; ++doc)
+    dref[(size_t)doc] = (rec_off16[(size_t)doc] << 16) | (h.fwd_offsets[(size_t)doc + 1] - h.fwd_offsets[(size_t)doc]);
+}
+
+void pack_narrow(const std::vector<uint64_t>& v, std::vector<uint32_t>* out) {
+  std::vector<uint32_t>& o = *out;
+  o.assign(v.size(), 0);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < (int64_t)v.size(); ++i) o[(size_t)i] = (uint32_t)v[(size_t)i];
+}
+
+// Split point of every summary row at half the list's block ids (rows are ascending in block id,
+// validate_desc): stage 1 gives each half of a list to its own wavefront.
+void pack_row_mid(const HostIndex& h, std::vector<uint16_t>* out) {
+  std::vector<uint16_t>& mid = *out;
+  mid.assign(h.n_rows(), 0);
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t c = 0; c < (int64_t)h.dim; ++c) {
+    const uint64_t nb = h.list_block_start[(size_t)c + 1] - h.list_block_start[(size_t)c];
+    const uint16_t half = (uint16_t)((nb + 1) / 2);
+    for (uint64_t r = h.list_row_start[(size_t)c]; r < h.list_row_start[(size_t)c + 1]; ++r) {
+      const uint16_t* b = h.sum_bid.data() + h.row_ptr[r];
+      const uint16_t* e = h.sum_bid.data() + h.row_ptr[r + 1];
+      mid[r] = (uint16_t)(std::lower_bound(b, e, half) - b);
+    }
+  }
+}
+
+// Dequantised summary values: code * quant + min with the reference's two roundings
+// (src/quantized_summary.rs:102-104; this file is compiled with -ffp-contract=off).
+void pack_sum_deq(const HostIndex& h, std::vector<float>* out) {
+  std::vector<float>& deq = *out;
+  deq.assign(h.n_entries(), 0.0f);
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int64_t c = 0; c < (int64_t)h.dim; ++c) {
+    const uint64_t b0 = h.list_block_start[(size_t)c];
+    for (uint64_t r = h.list_row_start[(size_t)c]; r < h.list_row_start[(size_t)c + 1]; ++r)
+      for (uint64_t e = h.row_ptr[r]; e < h.row_ptr[r + 1]; ++e) {
+        const uint64_t blk = b0 + h.sum_bid[e];
+        const volatile float t = (float)h.sum_code[e] * h.blk_quant[blk];
+        deq[e] = t + h.blk_min[blk];
+      }
+  }
+}
+
+}  // namespace sgpu
