@@ -187,6 +187,7 @@ sgpu_status sgpu_index_upload(sgpu_index* idx, int32_t device);
  * GPU (hipMemcpyPeer: xGMI on an MI355X node). With more than one replica, sgpu_batch_search shards a
  * batch contiguously over them, one host thread per device, and returns the rows in input order -
  * what the reference's rayon loop over queries does on host cores (src/pylib/mod.rs:629-652, 1129-1145).
+ * Calls with fewer than two queries per replica (sgpu_search) are not cut: the replicas take them in turn.
  * A device id may be listed more than once (replicas sharing a device; used to test the path on a
  * single-GPU box). Replaces any earlier upload. */
 sgpu_status sgpu_index_upload_many(sgpu_index* idx, const int32_t* device_ids, uint32_t n);

@@ -33,7 +33,7 @@ sgpu_status batch_fetch(DeviceIndex* d, Lane* lane, sgpu_batch* b, uint32_t k, f
                         uint32_t* out_n);
 sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out);
 sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
-                          const float* vals, uint32_t nq, const sgpu_search_params& sp, sgpu_batch** slot);
+                          const float* vals, uint32_t nq, uint32_t q_base, const sgpu_search_params& sp, sgpu_batch** slot);
 sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_scores, uint64_t* out_ids, uint32_t* out_n);
 sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list, const uint32_t* comps,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
@@ -161,6 +161,7 @@ uint32_t sgpu_index_replicas(const sgpu_index* idx) { return idx ? (uint32_t)idx
 
 sgpu_status sgpu_index_set_knn(sgpu_index* idx, const uint32_t* neighbours, uint64_t n_total, uint32_t knn_dim) {
   if (!idx || (n_total && !neighbours)) return fail(SGPU_EINVAL, "null argument");
+  if (n_total && knn_dim == 0) return fail(SGPU_EINVAL, "knn_dim == 0 with a non-empty neighbour array");
   for (uint64_t i = 0; i < n_total; ++i)
     if (neighbours[i] >= idx->host.n_docs) return fail(SGPU_EINVAL, "neighbour id >= n_docs");
   try {
@@ -187,10 +188,14 @@ sgpu_status sgpu_index_get_knn(const sgpu_index* idx, const uint32_t** neighbour
 
 sgpu_status sgpu_index_build_knn(sgpu_index* idx, uint32_t nknn) {
   if (!idx) return fail(SGPU_EINVAL, "null argument");
-  sgpu_status st = build_knn_on_device(idx->dev, idx->host, nknn);   // searches run on replica 0
-  for (size_t i = 1; st == SGPU_OK && i < idx->replicas.size(); ++i)
-    st = device_index_set_knn(idx->replicas[i], idx->host.knn, idx->host.knn_dim);
-  return st;
+  try {
+    sgpu_status st = build_knn_on_device(idx->dev, idx->host, nknn);   // searches run on replica 0
+    for (size_t i = 1; st == SGPU_OK && i < idx->replicas.size(); ++i)
+      st = device_index_set_knn(idx->replicas[i], idx->host.knn, idx->host.knn_dim);
+    return st;
+  } catch (const std::exception&) {
+    return fail(SGPU_ENOMEM, "out of host memory building the kNN graph");
+  }
 }
 
 uint64_t sgpu_index_device_bytes(const sgpu_index* idx) { return idx ? device_index_bytes(idx->dev) : 0; }
@@ -279,7 +284,7 @@ void sgpu_batch_destroy(sgpu_batch* batch) { batch_free(batch); }
 // chunk i+1 (validation, launch plan, staging of the H2D) runs while the GPU searches chunk i, and
 // the workgroups of chunk i+1 fill the CUs that chunk i's tail leaves idle.
 static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
-                                const float* vals, uint32_t nq, const sgpu_search_params& params,
+                                const float* vals, uint32_t nq, uint32_t q_base, const sgpu_search_params& params,
                                 float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n) {
   static const uint32_t chunk_min = [] {
     const char* v = std::getenv("SGPU_CHUNK_MIN");
@@ -292,6 +297,14 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
   Job jobs[4];
   uint32_t n_jobs = 1;
   if (chunk_min && nq >= 2 * chunk_min) n_jobs = std::min<uint32_t>(4, nq / chunk_min);
+  std::vector<uint64_t> off;   // a chunk's offsets, rebased (sized here: nothing below allocates host memory)
+  if (n_jobs > 1) {
+    try {
+      off.resize((size_t)nq / 2 + 2);
+    } catch (const std::exception&) {
+      n_jobs = 1;
+    }
+  }
   jobs[0].lane = lane_acquire(d);
   for (uint32_t j = 1; j < n_jobs; ++j) {
     jobs[j].lane = lane_try_acquire(d);
@@ -304,24 +317,22 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
   sgpu_status st = SGPU_OK;
   std::string msg;
   uint32_t launched = 0;
-  if (n_jobs > 1) {   // errors name the query by its index in the caller's batch, not in a chunk
+  if (n_jobs > 1) {   // the offsets of the whole shard hold before a chunk is launched (each chunk checks its own components)
     uint32_t max_nnz = 0;
-    st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz);
+    st = q_off[0] != 0 ? fail(SGPU_EINVAL, "q_off[0] must be 0") : validate_query_offsets(q_off, nq, q_base, &max_nnz);
     if (st != SGPU_OK) msg = last_error();
   }
-  std::vector<uint64_t> off;
   for (uint32_t j = 0; j < n_jobs && st == SGPU_OK; ++j) {
     Job& jb = jobs[j];
     jb.q0 = (uint32_t)((uint64_t)nq * j / n_jobs);
     jb.q1 = (uint32_t)((uint64_t)nq * (j + 1) / n_jobs);
     const uint64_t* qo = q_off;
     if (n_jobs > 1) {
-      off.resize(jb.q1 - jb.q0 + 1);
       for (uint32_t q = jb.q0; q <= jb.q1; ++q) off[q - jb.q0] = q_off[q] - q_off[jb.q0];
       qo = off.data();
     }
     st = staged_launch(d, jb.lane, dim, qo, comps ? comps + q_off[jb.q0] : nullptr, vals ? vals + q_off[jb.q0] : nullptr,
-                       jb.q1 - jb.q0, params, lane_scratch(jb.lane));
+                       jb.q1 - jb.q0, q_base + jb.q0, params, lane_scratch(jb.lane));
     if (st == SGPU_OK) ++launched;
     else msg = last_error();
   }
@@ -347,32 +358,61 @@ sgpu_status sgpu_batch_search(sgpu_index* idx, const uint64_t* q_off, const uint
   if (idx->replicas.empty()) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
   if (q_off[nq] && (!comps || !vals)) return fail(SGPU_EINVAL, "null argument");
   const uint32_t n_rep = (uint32_t)idx->replicas.size();
-  if (n_rep == 1 || nq < 2 * n_rep)
-    return search_shard(idx->dev, idx->host.dim, q_off, comps, vals, nq, *params, out_scores, out_doc_ids, out_n);
+  if (n_rep == 1) return search_shard(idx->dev, idx->host.dim, q_off, comps, vals, nq, 0, *params, out_scores, out_doc_ids, out_n);
+  if (nq < 2 * n_rep) {   // too small to shard (single queries of a serving loop): the replicas take such calls in turn
+    DeviceIndex* d = idx->replicas[idx->next_replica.fetch_add(1, std::memory_order_relaxed) % n_rep];
+    return search_shard(d, idx->host.dim, q_off, comps, vals, nq, 0, *params, out_scores, out_doc_ids, out_n);
+  }
   // Index replicated on several GPUs: contiguous shards of the batch, one host thread per GPU, no
   // collective; results land in input order (the reference's rayon loop over queries,
   // src/pylib/mod.rs:629-652, 1129-1145, becomes one shard per device).
-  std::vector<sgpu_status> sts(n_rep, SGPU_OK);
-  std::vector<std::string> msgs(n_rep);
-  std::vector<std::thread> threads;
-  const uint32_t k = params->k;
-  for (uint32_t r = 0; r < n_rep; ++r) {
-    const uint32_t q0 = (uint32_t)((uint64_t)nq * r / n_rep), q1 = (uint32_t)((uint64_t)nq * (r + 1) / n_rep);
-    threads.emplace_back([=, &sts, &msgs]() {
-      std::vector<uint64_t> off(q1 - q0 + 1);
-      for (uint32_t q = q0; q <= q1; ++q) off[q - q0] = q_off[q] - q_off[q0];
-      sts[r] = search_shard(idx->replicas[r], idx->host.dim, off.data(), comps ? comps + q_off[q0] : nullptr,
-                            vals ? vals + q_off[q0] : nullptr, q1 - q0, *params, out_scores + (size_t)q0 * k,
-                            out_doc_ids + (size_t)q0 * k, out_n + q0);
-      if (sts[r] != SGPU_OK) msgs[r] = last_error();
-    });
+  {   // the offsets of the whole batch hold before it is cut (each shard checks its own components)
+    uint32_t max_nnz = 0;
+    if (q_off[0] != 0) return fail(SGPU_EINVAL, "q_off[0] must be 0");
+    const sgpu_status vst = validate_query_offsets(q_off, nq, 0, &max_nnz);
+    if (vst != SGPU_OK) return vst;
   }
-  for (auto& t : threads) t.join();
-  for (uint32_t r = 0; r < n_rep; ++r)
-    if (sts[r] != SGPU_OK) {
-      last_error() = msgs[r];
-      return sts[r];
+  const uint32_t k = params->k;
+  try {
+    std::vector<sgpu_status> sts(n_rep, SGPU_OK);
+    std::vector<std::string> msgs(n_rep);
+    std::vector<std::vector<uint64_t>> offs(n_rep);   // every shard's offsets, rebased; sized before a thread starts
+    for (uint32_t r = 0; r < n_rep; ++r) {
+      const uint32_t q0 = (uint32_t)((uint64_t)nq * r / n_rep), q1 = (uint32_t)((uint64_t)nq * (r + 1) / n_rep);
+      offs[r].resize(q1 - q0 + 1);
+      for (uint32_t q = q0; q <= q1; ++q) offs[r][q - q0] = q_off[q] - q_off[q0];
     }
+    auto shard = [&](uint32_t r) {
+      const uint32_t q0 = (uint32_t)((uint64_t)nq * r / n_rep), q1 = (uint32_t)((uint64_t)nq * (r + 1) / n_rep);
+      try {
+        sts[r] = search_shard(idx->replicas[r], idx->host.dim, offs[r].data(), comps ? comps + q_off[q0] : nullptr,
+                              vals ? vals + q_off[q0] : nullptr, q1 - q0, q0, *params, out_scores + (size_t)q0 * k,
+                              out_doc_ids + (size_t)q0 * k, out_n + q0);
+        if (sts[r] != SGPU_OK) msgs[r] = last_error();
+      } catch (const std::exception&) {
+        sts[r] = SGPU_ENOMEM;
+      }
+    };
+    std::vector<std::thread> threads;
+    threads.reserve(n_rep);
+    for (uint32_t r = 1; r < n_rep; ++r) {
+      try {
+        threads.emplace_back(shard, r);
+      } catch (const std::exception&) {   // no thread to be had: the shard runs on this one
+        shard(r);
+      }
+    }
+    shard(0);   // the calling thread drives replica 0
+    for (auto& t : threads) t.join();
+    for (uint32_t r = 0; r < n_rep; ++r)
+      if (sts[r] != SGPU_OK) {
+        if (msgs[r].empty()) return fail(sts[r], "out of host memory searching shard %u", r);
+        last_error() = msgs[r];
+        return sts[r];
+      }
+  } catch (const std::exception&) {
+    return fail(SGPU_ENOMEM, "out of host memory sharding a query batch");
+  }
   return SGPU_OK;
 }
 

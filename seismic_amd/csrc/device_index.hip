@@ -9,8 +9,6 @@
 #include <unordered_map>
 #include <vector>
 
-#include <omp.h>
-
 #include "device_types.hpp"
 #include "host_index.hpp"
 
@@ -521,6 +519,7 @@ sgpu_status batch_create(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_
     b = nullptr;
     *out = nullptr;
   }
+  std::vector<uint32_t> off32;
   try {
     if (!b) b = new sgpu_batch();
     b->device = d->device;
@@ -533,11 +532,12 @@ sgpu_status batch_create(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_
     b->h_off.assign(q_off, q_off + nq + 1);
     b->h_comp.assign(comps, comps + nnz);
     b->h_val.assign(vals, vals + nnz);
+    off32.resize((size_t)nq + 1);
   } catch (const std::bad_alloc&) {
     if (!reuse) delete b;
+    else b->nq = 0;   // the recycled batch stays valid, and empty
     return fail(SGPU_ENOMEM, "out of host memory creating a query batch");
   }
-  std::vector<uint32_t> off32(nq + 1);
   for (uint32_t q = 0; q <= nq; ++q) off32[q] = (uint32_t)q_off[q];
   bool ok = true;
   if (!reuse) {
@@ -994,13 +994,14 @@ static inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // Validates, plans, stages and launches one search of `nq` queries on `lane`: one H2D, the kernel, one
 // D2H, all enqueued; staged_finish waits and hands the rows out. *slot is the lane's recycled batch.
+// (q_base: the index of the first query in the caller's batch, for error messages.)
 sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
-                          const float* vals, uint32_t nq, const sgpu_search_params& sp, sgpu_batch** slot) {
+                          const float* vals, uint32_t nq, uint32_t q_base, const sgpu_search_params& sp, sgpu_batch** slot) {
   if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
   if (sp.k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
   if (sp.k > 1024) return fail(SGPU_ELIMIT, "k = %u exceeds the heap limit of 1024", sp.k);
   uint32_t max_nnz = 0;
-  sgpu_status st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz);
+  sgpu_status st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz, q_base);
   if (st != SGPU_OK) return st;
   HIP_TRY(hipSetDevice(d->device));
   const uint64_t nnz = q_off[nq];
@@ -1068,17 +1069,21 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   b->out_ids = (uint64_t*)(b->arena_dev + r_id);
   b->out_stats = nullptr;
   HIP_TRY(hipMemcpyAsync(b->arena_dev, hs, in_bytes, hipMemcpyHostToDevice, lane->stream));
+  // from here on a failure waits for the stream: the lane (and its pinned arena) goes back to the pool
+  hipError_t he = hipSuccess;
   {
     std::lock_guard<std::mutex> lock(d->mu);   // the occupancy cache is shared by the lanes
     LaunchArgs a{};
     st = configure(d, lane, b, sp, MODE_SEARCH, &a);
-    if (st != SGPU_OK) {
-      (void)hipStreamSynchronize(lane->stream);
-      return st;
-    }
-    HIP_TRY(launch_search(a));
+    if (st == SGPU_OK) he = launch_search(a);
   }
-  HIP_TRY(hipMemcpyAsync(hs + r_n, b->arena_dev + r_n, b->out_bytes, hipMemcpyDeviceToHost, lane->stream));
+  if (st == SGPU_OK && he == hipSuccess)
+    he = hipMemcpyAsync(hs + r_n, b->arena_dev + r_n, b->out_bytes, hipMemcpyDeviceToHost, lane->stream);
+  if (st != SGPU_OK || he != hipSuccess) {
+    (void)hipStreamSynchronize(lane->stream);
+    if (st == SGPU_OK) st = fail(SGPU_EDEVICE, "launch of the search failed: %s", hipGetErrorString(he));
+    return st;
+  }
   return SGPU_OK;
 }
 

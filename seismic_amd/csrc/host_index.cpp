@@ -145,17 +145,27 @@ sgpu_status host_index_from_desc(const sgpu_index_desc& d, HostIndex* out) {
 }
 
 // Query batch validation shared by the search entry points and the exact search.
-sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t* comps, const float* vals,
-                             uint32_t nq, uint32_t* max_nnz) {
-  if (!q_off || q_off[0] != 0) return fail(SGPU_EINVAL, "q_off[0] must be 0");
+sgpu_status validate_query_offsets(const uint64_t* q_off, uint32_t nq, uint32_t q_base, uint32_t* max_nnz) {
+  if (!q_off) return fail(SGPU_EINVAL, "null q_off");
   uint32_t mx = 0;
   for (uint32_t q = 0; q < nq; ++q) {
     if (q_off[q + 1] < q_off[q]) return fail(SGPU_EINVAL, "q_off not monotone");
     const uint64_t n = q_off[q + 1] - q_off[q];
-    if (n > 0xffffu) return fail(SGPU_ELIMIT, "query %u has %llu components (limit 65535)", q, (unsigned long long)n);
+    if (n > 0xffffu)
+      return fail(SGPU_ELIMIT, "query %u has %llu components (limit 65535)", q_base + q, (unsigned long long)n);
     mx = std::max<uint32_t>(mx, (uint32_t)n);
   }
-  if (q_off[nq] >= 0xffffffffull) return fail(SGPU_ELIMIT, "batch too large");
+  if (q_off[nq] - q_off[0] >= 0xffffffffull) return fail(SGPU_ELIMIT, "batch too large");
+  *max_nnz = mx;
+  return SGPU_OK;
+}
+
+sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t* comps, const float* vals,
+                             uint32_t nq, uint32_t* max_nnz, uint32_t q_base) {
+  if (!q_off || q_off[0] != 0) return fail(SGPU_EINVAL, "q_off[0] must be 0");
+  uint32_t mx = 0;
+  const sgpu_status ost = validate_query_offsets(q_off, nq, q_base, &mx);
+  if (ost != SGPU_OK) return ost;
   if (q_off[nq] && (!comps || !vals)) return fail(SGPU_EINVAL, "null query arrays");
   // InvertedIndexBase::search asserts sorted components (reference src/inverted_index.rs:172-175)
   // and indexes posting_lists[component] (bounds panic, :193); duplicates are rejected too.
@@ -169,7 +179,7 @@ sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t
       else if (i > q_off[q] && comps[i] <= comps[i - 1]) bad_kind = 2;
       else if (std::isnan(vals[i])) bad_kind = 3;
     }
-    if (bad_kind) bad_q = q;
+    if (bad_kind) bad_q = q_base + q;
   }
   if (bad_kind == 1) return fail(SGPU_EINVAL, "query %u: component >= dim", bad_q);
   if (bad_kind == 2) return fail(SGPU_EINVAL, "query %u: components must be strictly ascending", bad_q);

@@ -1,6 +1,7 @@
 // host_index.hpp — canonical host-side index (the arrays of sgpu_index_desc, owned).
 #pragma once
 #include <cstdint>
+#include <atomic>
 #include <vector>
 
 #include "common.hpp"
@@ -59,9 +60,12 @@ sgpu_status host_index_load(const char* path, HostIndex* out);
 sgpu_status host_index_convert(const HostIndex& src, uint32_t value_type, HostIndex* out);
 
 // CSR query batch: q_off[0] == 0 and monotone, components strictly ascending and < dim, no NaN,
-// at most 65535 components per query; *max_nnz = the longest query
+// at most 65535 components per query; *max_nnz = the longest query. Error messages name query q_base + q
+// (a chunk or shard of a larger batch reports the caller's numbering).
 sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t* comps, const float* vals,
-                             uint32_t nq, uint32_t* max_nnz);
+                             uint32_t nq, uint32_t* max_nnz, uint32_t q_base = 0);
+// the offsets alone (monotone, query and batch size limits): what has to hold before a batch is cut
+sgpu_status validate_query_offsets(const uint64_t* q_off, uint32_t nq, uint32_t q_base, uint32_t* max_nnz);
 // pack_index.cpp: the host half of the upload (HBM layout of DESIGN.md section 2), on all host cores
 void pack_record_offsets(const HostIndex& h, uint64_t line16, std::vector<uint64_t>* rec_off16);
 void pack_records(const HostIndex& h, const std::vector<uint64_t>& rec_off16, std::vector<uint8_t>* fwd);
@@ -89,4 +93,5 @@ struct sgpu_index {
   sgpu::HostIndex host;
   std::vector<sgpu::DeviceIndex*> replicas;   // one per device the index was uploaded to
   sgpu::DeviceIndex* dev = nullptr;           // replicas[0] (null before upload)
+  std::atomic<uint32_t> next_replica{0};      // calls too small to shard go to the replicas in turn
 };

@@ -30,6 +30,7 @@ Documented deviations (DESIGN.md "Boundary"):
     document through the same kernel; knn files are numpy .npy (the reference's *.knn.seismic
     uses vectorium's serializer).
 """
+import ctypes as C
 import gzip
 import io
 import json
@@ -349,6 +350,30 @@ class _IndexBase:
             dim = nknn
         self._ix.set_knn(nb, dim)
 
+    @property
+    def is_empty(self):
+        return self.len == 0
+
+    def get(self, id):
+        """Document `id` of the forward index -> (component ids, values as f32); reference
+        src/pylib/mod.rs:157-165, 797-805 (`dataset().get(id)`, values widened with `to_f32`)."""
+        d = self._ix.desc
+        if not 0 <= id < d.n_docs:
+            raise IndexError("document %d out of range (0..%d)" % (id, d.n_docs))   # the reference panics
+        a, e = int(d.fwd_offsets[id]), int(d.fwd_offsets[id + 1])
+        if e == a:
+            return [], []
+        cdt = np.uint16 if d.comp_width == 2 else np.uint32
+        comps = np.ctypeslib.as_array((C.c_uint8 * ((e - a) * d.comp_width)).from_address(d.fwd_comps + a * d.comp_width))
+        comps = comps.view(cdt)
+        if d.value_type == 0:
+            vals = np.ctypeslib.as_array((C.c_uint16 * (e - a)).from_address(d.fwd_vals + a * 2)).view(np.float16)
+            vals = vals.astype(np.float32)
+        else:
+            codes = np.ctypeslib.as_array((C.c_uint8 * (e - a)).from_address(d.fwd_vals + a))
+            vals = codes.astype(np.float32) * np.float32(d.val_scale)
+        return [int(c) for c in comps], [float(v) for v in vals]
+
     def get_doc_ids_in_postings(self, list_id):
         d = self._ix.desc
         if not 0 <= list_id < d.dim:
@@ -458,6 +483,8 @@ class _RawBase:
     len = _IndexBase.len
     nnz = _IndexBase.nnz
     knn_len = _IndexBase.knn_len
+    is_empty = _IndexBase.is_empty
+    get = _IndexBase.get
     get_doc_ids_in_postings = _IndexBase.get_doc_ids_in_postings
     print_space_usage_byte = _IndexBase.print_space_usage_byte
 

@@ -103,6 +103,15 @@ def test_toy_dataset_plumbing_and_golden(tmp_path):
             assert got == row["seismic_sorted_%s" % srt]
         # the empty document (id 18) is never retrieved
         assert all(d != "18" for d, _ in row["seismic_sorted_True"])
+    # get(id): the stored document (reference src/pylib/mod.rs:157-165): component ids and f16 values as f32
+    _, dvecs, _ = seismic_amd.index.read_jsonl(os.path.join(GOLD, "toy", "documents.jsonl"))
+    for doc in (0, 7, 18, 19):
+        gc, gv = ix.get(doc)
+        want = sorted((ix._tm[t], float(np.float32(np.float16(v)))) for t, v in dvecs[doc].items())
+        assert list(zip(gc, gv)) == want
+    assert ix.get(18) == ([], []) and not ix.is_empty
+    with pytest.raises(IndexError):
+        ix.get(20)
     # persistence of the string-keyed wrapper
     ix.save(str(tmp_path / "toy"))
     jx = seismic_amd.SeismicIndex.load(str(tmp_path / "toy"), upload=False)
@@ -302,6 +311,10 @@ def test_convert_to_fixed_u8_host_side(tmp_path):
     for i in range(12):
         es, ei = orc.exact_search(u8.desc, qc[q_off[i]:q_off[i + 1]], qv[q_off[i]:q_off[i + 1]], 10, orc.ORDER_SEQ)
         assert np.array_equal(ids[i, :n[i]], ei) and np.array_equal(sc[i, :n[i]], es)
+    w = seismic_amd.SeismicIndexRaw(u8, upload=False)                     # get() of a fixed-u8 index: code * step
+    gc, gv = w.get(5)
+    assert gc == [int(c) for c in comps[off[5]:off[6]]]
+    assert np.array_equal(np.array(gv, np.float32), deq[off[5]:off[6]])
     back = u8.convert(0)                                                  # and back to f16: values are the dequantised codes
     assert back.desc.value_type == 0
     with pytest.raises(_native.SeismicHipError):

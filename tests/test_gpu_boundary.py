@@ -110,6 +110,24 @@ def test_replicas_shard_a_batch_in_process():
     q = random_queries(67, 101, dim, 3, 50)   # 101: uneven shards
     for (k, cut, hf, srt) in [(10, 4, 1.0, False), (20, 8, 0.8, True)]:
         _same(ix.batch_search(*q, k, cut, hf, srt), orc.batch_search(ix.desc, *q, k, cut, hf, srt)[:3])
+    # calls too small to shard (single queries of a serving loop) go to the replicas in turn
+    q_off, q_comps, q_vals = q
+    want = orc.batch_search(ix.desc, *q, 10, 4, 1.0, False)
+    for i in range(2 * len(devs) + 1):
+        a, e = int(q_off[i]), int(q_off[i + 1])
+        sc, ids, n = ix.batch_search(np.array([0, e - a], np.uint64), q_comps[a:e], q_vals[a:e], 10, 4, 1.0, False)
+        assert int(n[0]) == int(want[2][i])
+        assert np.array_equal(ids[0, :n[0]], want[1][i, :n[0]]) and np.array_equal(sc[0, :n[0]], want[0][i, :n[0]])
+    # errors name the query by its index in the caller's batch, not in a shard; offsets are checked before the cut
+    bad_c = q_comps.copy()
+    bad_c[int(q_off[77])] = dim + 1
+    with pytest.raises(_native.SeismicHipError) as e:
+        ix.batch_search(q_off, bad_c, q_vals, 10, 4, 1.0, False)
+    assert "query 77" in str(e.value)
+    bad_off = q_off.copy()
+    bad_off[50] = bad_off[49] - 1 if bad_off[49] else bad_off[51] + 1
+    with pytest.raises(_native.SeismicHipError):
+        ix.batch_search(bad_off, q_comps, q_vals, 10, 4, 1.0, False)
     # device-resident batches on a chosen replica
     b = _native.DeviceBatch(ix, *q, 10, replica=len(devs) - 1)
     b.run(10, 4, 1.0, False)
