@@ -80,6 +80,10 @@ def parse_args():
     ap.add_argument("--no-recall", action="store_true", help="skip recall@k vs exact")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end sgpu_batch_search measurement")
+    ap.add_argument("--no-weak-leg", action="store_true",
+                    help="N>1, strong scaling: skip the extra replicas (weak scaling) measurement")
+    ap.add_argument("--all-legs", action="store_true",
+                    help="N>1: also run the single-GPU legs (end to end, latency, recall) on rank 0")
     ap.add_argument("--no-accounting", action="store_true",
                     help="skip the counted passes (PMC profiling runs: only the timed kernel variant is dispatched)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline time budget")
@@ -355,6 +359,36 @@ def main():
                 np.array_equal(ref[2], full[2]) and np.array_equal(ref[1], full[1])
                 and np.array_equal(ref[0].view(np.uint32), full[0].view(np.uint32)))
 
+    # ---- N>1: the same GPUs as N independent replicas (weak scaling), reported NEXT to `value`: every
+    # rank searches a whole batch of args.queries per step (rank r starts at batch r), same barriers,
+    # same max-over-ranks clock. Strong scaling pays the launch tail of 1/N-size launches; this leg does not.
+    if world > 1 and scaling == "strong" and not args.no_weak_leg:
+        def whole(i):
+            lo, hi = i * args.queries, (i + 1) * args.queries
+            o0, o1 = int(a_off[lo]), int(a_off[hi])
+            return (a_off[lo:hi + 1] - a_off[lo]).astype(np.uint64), a_comp[o0:o1], a_val[o0:o1]
+        wb = [_native.DeviceBatch(index, *whole((i + rank) % n_batches), args.k) for i in range(n_batches)]
+        for i in range(args.warmup):
+            wb[i % n_batches].run(args.k, args.query_cut, args.heap_factor, srt, sync=False)
+        wb[0].sync()
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            wb[(args.warmup + i) % n_batches].run(args.k, args.query_cut, args.heap_factor, srt, sync=False)
+        wstats = wb[0].sync()
+        barrier()
+        welapsed = time.perf_counter() - t0
+        t = torch.tensor([welapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        welapsed = float(t.item())
+        out["replicas_weak_scaling"] = {
+            "value": world * args.queries * args.steps / welapsed, "unit": "queries/s",
+            "ms_per_step": welapsed * 1e3 / args.steps, "queries_per_gpu_per_step": args.queries,
+            "kernel_ms_rank0": float(wstats.kernel_ms),
+            "note": "N independent replicas, one whole batch per GPU and step; `value` above is ONE batch sharded over the GPUs",
+        }
+        del wb
+
     if rank == 0 and args.results_tsv:
         _native.write_results_tsv(args.results_tsv, gsc, gid, gn)
     if rank == 0 and args.groundtruth:
@@ -367,6 +401,10 @@ def main():
     s_off = s_off[:ns + 1].copy()
     s_comp, s_val = s_comp[:int(s_off[ns])], s_val[:int(s_off[ns])]
 
+    # the single-GPU legs (end to end, batch-1 latency, recall, cpu_baseline) belong to the N=1 line
+    if world > 1 and not args.all_legs:
+        args.no_e2e = args.no_latency = args.no_recall = True
+        out["single_gpu_legs"] = "skipped at N>1 (end_to_end, latency, recall, cpu_baseline: see the N=1 line; --all-legs runs them)"
     if rank == 0 and not args.no_e2e:
         # End to end through the drop-in entry point, host buffers in and out (sgpu_batch_search:
         # validation + H2D of the queries + launch plan + kernel + D2H of the results), on the timed

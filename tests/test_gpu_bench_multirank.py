@@ -43,6 +43,10 @@ def test_two_ranks_strong_scaling_is_the_single_gpu_answer(tmp_path):
     assert out["config"]["launch"]["queries_per_launch"] in (750, 751)
     assert out["roofline"]["counted_pass_identical"] is True
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    # the same ranks as independent replicas (a whole batch per rank and step), reported next to `value`
+    w = out["replicas_weak_scaling"]
+    assert w["queries_per_gpu_per_step"] == 1501 and w["value"] > 0 and w["ms_per_step"] > 0
+    assert "single_gpu_legs" in out and "end_to_end" not in out
 
 
 def test_two_ranks_weak_scaling(tmp_path):
