@@ -157,6 +157,10 @@ def _to_csr(vecs, token_map):
 def _resolve(tokens, values, token_map):
     """resolve_query_tokens (reference src/inverted_index_wrapper.rs:75-91): unknown tokens are
     dropped silently, the rest is sorted by component id."""
+    if isinstance(tokens, np.ndarray):
+        tokens = tokens.ravel().tolist()   # python strings in one C-level pass
+    if isinstance(values, np.ndarray):
+        values = values.ravel().tolist()
     pairs = sorted((token_map[t], float(v)) for t, v in zip(tokens, values) if t in token_map)
     # a token repeated in the query would give a duplicate component; keep the first, as a
     # dict-built query (the documented way to make one) cannot contain duplicates
@@ -243,6 +247,7 @@ class _IndexBase:
         self._tm = token_map
         self._doc_ids = doc_ids
         self._contents = contents
+        self._doc_pos = None
         self._device = device
         self._uploaded = False
         if upload:
@@ -402,20 +407,20 @@ class _IndexBase:
     def get_doc_text(self, doc_id):
         if self._contents is None:
             return None
-        try:
-            return self._contents[self._doc_ids.index(doc_id)]
-        except ValueError:
-            return None
+        if self._doc_pos is None:   # built on first use: doc id -> position
+            self._doc_pos = {d: i for i, d in enumerate(self._doc_ids)}
+        i = self._doc_pos.get(doc_id)
+        return None if i is None else self._contents[i]
 
     # ---- search -------------------------------------------------------
     def _remap(self, query_id, sc, ids, n):
-        return [(str(query_id), float(sc[i]), self._doc_ids[int(ids[i])]) for i in range(int(n))]
+        n, q, names = int(n), str(query_id), self._doc_ids
+        return [(q, s, names[i]) for s, i in zip(sc[:n].tolist(), ids[:n].tolist())]
 
     def search(self, query_id, query_components, query_values, k, query_cut, heap_factor, n_knn=0, sorted=True):
         """-> [(query_id, score, doc_id)], best first (reference src/pylib/mod.rs:490-533)."""
         self._ensure_device()
-        c, v = _resolve([str(t) for t in np.asarray(query_components).ravel()],
-                        np.asarray(query_values, np.float32).ravel(), self._tm)
+        c, v = _resolve(np.asarray(query_components).astype(str), np.asarray(query_values, np.float32), self._tm)
         sc, ids = self._ix.search(c, v, k, query_cut, heap_factor, first_sorted=bool(sorted), n_knn=n_knn)
         return self._remap(query_id, sc, ids, len(ids))
 
@@ -428,7 +433,7 @@ class _IndexBase:
         off = np.zeros(len(qids) + 1, np.uint64)
         cs, vs = [], []
         for i, (qc, qv) in enumerate(zip(query_components, query_values)):
-            c, v = _resolve([str(t) for t in np.asarray(qc).ravel()], np.asarray(qv, np.float32).ravel(), self._tm)
+            c, v = _resolve(np.asarray(qc).astype(str), np.asarray(qv, np.float32), self._tm)
             cs.append(c)
             vs.append(v)
             off[i + 1] = off[i] + len(c)
