@@ -158,12 +158,16 @@ def main():
     cache_dir = args.index_cache or tempfile.gettempdir()
     path = os.path.join(cache_dir, tag + ".idx")
     qpath = os.path.join(cache_dir, tag + "_q%d_b%d_w%d_%s.bin" % (args.queries, n_batches, world, scaling))
-    t_gen = t_build = 0.0
     # query sets: strong scaling = the same n_batches global batches on every rank (each takes its
     # shard); weak scaling = n_batches batches per rank
     n_sets = n_batches * (world if scaling == "weak" else 1)
-    if rank == 0:
+    t_gen = t_build = 0.0
+
+    def prepare(write_files):
+        """Documents -> index (a cached file when there is one) -> query sets. Deterministic: every rank
+        that runs it holds the same data."""
         index = None
+        t_gen = t_build = 0.0
         if os.path.exists(path):
             try:
                 index = _native.NativeIndex.load(path)
@@ -175,29 +179,54 @@ def main():
             t0 = time.time()
             docs = _native.read_inner_format(args.documents) if args.documents else _native.synth(args.docs, args.dim, 42, 0)
             t_gen = time.time() - t0
+        wrote = True
         if index is None:
             t0 = time.time()
             dim = args.dim if not args.documents else max(args.dim, int(docs[1].max()) + 1)
             index = _native.NativeIndex.build(args.comp_width, dim, *docs, cfg)
             t_build = time.time() - t0
-            if world > 1 or args.index_cache:
+            if write_files and (world > 1 or args.index_cache):
                 tmp = "%s.tmp.%d" % (path, os.getpid())
-                index.save(tmp)
-                os.replace(tmp, path)     # the other ranks only ever see a complete file
+                try:
+                    if os.environ.get("SGPU_BENCH_NO_HANDOFF"):   # (test hook: exercise the path below)
+                        raise OSError("hand-off disabled by SGPU_BENCH_NO_HANDOFF")
+                    index.save(tmp)
+                    os.replace(tmp, path)     # the other ranks only ever see a complete file
+                except (_native.SeismicHipError, OSError) as e:   # e.g. no room in the temporary directory
+                    log("[bench] cannot hand the index over as a file (%s): every rank builds its own" % e)
+                    wrote = False
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
         if args.queries_file:
             allq = _native.read_inner_format(args.queries_file)
         else:
             allq = _native.synth(args.queries * n_sets, int(index.desc.dim), 43, 1, docs)
-        if world > 1:
+        if write_files and world > 1 and wrote:
             tmp = "%s.tmp.%d" % (qpath, os.getpid())
-            _native.write_inner_format(tmp, *allq)
-            os.replace(tmp, qpath)
-        del docs
+            try:
+                _native.write_inner_format(tmp, *allq)
+                os.replace(tmp, qpath)
+            except OSError:
+                wrote = False
+        return index, allq, t_gen, t_build, wrote
+
+    # rank 0 prepares and hands the index and the query sets over as files; if they cannot be written
+    # the other ranks prepare the same data themselves
+    handoff = True
+    if rank == 0:
+        index, allq, t_gen, t_build, handoff = prepare(True)
         log("[bench] documents ready in %.1fs, index built in %.1fs" % (t_gen, t_build))
     barrier()
+    if world > 1:
+        flag = [handoff]
+        dist.broadcast_object_list(flag, src=0)
+        handoff = bool(flag[0])
     if rank != 0:
-        index = _native.NativeIndex.load(path)
-        allq = _native.read_inner_format(qpath)
+        if handoff:
+            index = _native.NativeIndex.load(path)
+            allq = _native.read_inner_format(qpath)
+        else:
+            index, allq, _, _, _ = prepare(False)
     if args.value_type == "fixedu8":   # convert_dataset_into: same lists / blocks / summaries, u8 forward values
         index = index.convert(1)
     t0 = time.time()

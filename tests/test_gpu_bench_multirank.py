@@ -22,9 +22,9 @@ def _free_port():
     return p
 
 
-def _run(scaling, tmp_path):
+def _run(scaling, tmp_path, **extra_env):
     env = dict(os.environ, SGPU_BENCH_ONE_DEVICE="1", SGPU_BENCH_BACKEND="gloo", SGPU_INDEX_CACHE=str(tmp_path),
-               MASTER_ADDR="127.0.0.1")
+               MASTER_ADDR="127.0.0.1", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps",
            "3", "--warmup", "1", "--docs", "60000", "--queries", "1501", "--n-postings", "300", "--scaling", scaling,
@@ -50,7 +50,9 @@ def test_two_ranks_strong_scaling_is_the_single_gpu_answer(tmp_path):
 
 
 def test_two_ranks_weak_scaling(tmp_path):
-    out = _run("weak", tmp_path)
+    # (and without the file hand-off: when rank 0 cannot write the index, every rank builds its own)
+    out = _run("weak", tmp_path, SGPU_BENCH_NO_HANDOFF="1")
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".idx")]
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["config"]["launch"]["queries_per_launch"] == 1501
     assert out["value"] > 0
