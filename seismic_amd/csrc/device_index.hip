@@ -441,6 +441,9 @@ struct sgpu_batch_plan {   // per (batch, query_cut): LDS need and processing or
 
 struct sgpu_batch {
   std::vector<uint64_t> h_off;
+  std::vector<uint32_t> h_off32;   // what the device holds (the copies below read the batch's own arrays,
+                                   // which live as long as the batch: nothing depends on when a copy from
+                                   // pageable memory lets go of its source)
   std::vector<uint32_t> h_comp;
   std::vector<float> h_val;
   std::vector<sgpu_batch_plan> plans;
@@ -498,8 +501,8 @@ void batch_free(sgpu_batch* b) {
 }
 
 // Creates (or, when *out already holds a large enough batch of the same device, refills) a device
-// batch. The copies are enqueued on `lane`'s stream; the host arrays are pageable, so they are
-// staged before the calls return and the caller's buffers are not referenced afterwards.
+// batch. The copies are enqueued on `lane`'s stream from the batch's own host copies of the arrays;
+// the caller's buffers are not referenced after the call returns.
 sgpu_status batch_create(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
                          const float* vals, uint32_t nq, uint32_t k_max, sgpu_batch** out) {
   if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
@@ -519,7 +522,7 @@ sgpu_status batch_create(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_
     b = nullptr;
     *out = nullptr;
   }
-  std::vector<uint32_t> off32;
+  if (reuse) HIP_TRY(hipStreamSynchronize(lane->stream));   // earlier copies out of the batch's host arrays are done
   try {
     if (!b) b = new sgpu_batch();
     b->device = d->device;
@@ -532,13 +535,13 @@ sgpu_status batch_create(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_
     b->h_off.assign(q_off, q_off + nq + 1);
     b->h_comp.assign(comps, comps + nnz);
     b->h_val.assign(vals, vals + nnz);
-    off32.resize((size_t)nq + 1);
+    b->h_off32.resize((size_t)nq + 1);
   } catch (const std::bad_alloc&) {
     if (!reuse) delete b;
     else b->nq = 0;   // the recycled batch stays valid, and empty
     return fail(SGPU_ENOMEM, "out of host memory creating a query batch");
   }
-  for (uint32_t q = 0; q <= nq; ++q) off32[q] = (uint32_t)q_off[q];
+  for (uint32_t q = 0; q <= nq; ++q) b->h_off32[q] = (uint32_t)q_off[q];
   bool ok = true;
   if (!reuse) {
     // a recycled batch grows geometrically so that a stream of slightly different calls settles
@@ -560,10 +563,10 @@ sgpu_status batch_create(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_
     *out = nullptr;
     return fail(SGPU_ENOMEM, "hipMalloc failed creating a query batch");
   }
-  ok = hipMemcpyAsync(b->q_off, off32.data(), (nq + 1) * 4, hipMemcpyHostToDevice, lane->stream) == hipSuccess &&
+  ok = hipMemcpyAsync(b->q_off, b->h_off32.data(), (nq + 1) * 4, hipMemcpyHostToDevice, lane->stream) == hipSuccess &&
        (nnz == 0 ||
-        (hipMemcpyAsync(b->q_comp, comps, nnz * 4, hipMemcpyHostToDevice, lane->stream) == hipSuccess &&
-         hipMemcpyAsync(b->q_val, vals, nnz * 4, hipMemcpyHostToDevice, lane->stream) == hipSuccess));
+        (hipMemcpyAsync(b->q_comp, b->h_comp.data(), nnz * 4, hipMemcpyHostToDevice, lane->stream) == hipSuccess &&
+         hipMemcpyAsync(b->q_val, b->h_val.data(), nnz * 4, hipMemcpyHostToDevice, lane->stream) == hipSuccess));
   if (!ok) {
     (void)hipStreamSynchronize(lane->stream);
     batch_free(b);

@@ -19,7 +19,8 @@ bad = []
 t0 = time.time()
 # the committed test derives everything from the seed: run it for many more seeds
 orig = np.random.default_rng
-for seed in range(26, 226):
+LO, HI = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (26, 226)
+for seed in range(LO, HI):
     mp = MP()
     try:
         fz.test_differential.__wrapped__(seed, mp) if hasattr(fz.test_differential, "__wrapped__") else fz.test_differential(seed, mp)
@@ -27,7 +28,7 @@ for seed in range(26, 226):
         bad.append((seed, repr(e)[:300]))
     finally:
         mp.undo()
-print("fuzz seeds 26..225: %d failures in %.0f s" % (len(bad), time.time() - t0), bad[:5], flush=True)
+print("fuzz seeds %d..%d: %d failures in %.0f s" % (LO, HI - 1, len(bad), time.time() - t0), bad[:5], flush=True)
 # config 5 at full size vs the oracle
 dim, n_docs, nq = 200_000, 5_000_000, 200
 docs = _native.synth(n_docs, dim, 42, 0)
