@@ -17,6 +17,12 @@ where /root/reference exists; the GPU box only sees the committed outputs).
       (run here, where /root/reference exists) on its toy dataset - the inner binary format that
       SeismicIndexRaw.build / batch_search read (src/pylib/mod.rs:987,1127). Pins read_inner_format,
       write_inner_format and the sorted token numbering against bytes the reference wrote.
+  accuracy/case*_results.tsv, case*_groundtruth.tsv, expected.json
+      REFERENCE-GENERATED expected values: seeded result / ground-truth TSV pairs in the layout of
+      perf_inverted_index's dump (self-made inputs), and the accuracy the reference's own
+      `compute_accuracy` (scripts/run_experiments.py:287-309) returns for each pair. That function is
+      executed here straight from the reference's file (its module imports packages this image lacks,
+      so only that one function is compiled, with pandas); nothing of its text is kept in this repository.
 """
 import json
 import os
@@ -57,7 +63,56 @@ def reference_inner_format():
             shutil.copy(os.path.join(tmp, "data", f), os.path.join(dst, f))
 
 
+def reference_function(path, name, namespace):
+    """The function `name` of a reference Python file, compiled from the file where it lies."""
+    import ast
+    tree = ast.parse(open(path).read(), path)
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    exec(compile(ast.Module([node], []), path, "exec"), namespace)
+    return namespace[name]
+
+
+def reference_accuracy_cases():
+    import contextlib
+    import io
+    import pandas as pd
+    fn = reference_function("/root/reference/scripts/run_experiments.py", "compute_accuracy", {"pd": pd})
+    dst = os.path.join(HERE, "accuracy")
+    os.makedirs(dst, exist_ok=True)
+    rng = np.random.default_rng(77)
+    expected = {}
+    for case in range(4):
+        nq, k = [12, 30, 7, 1][case], [10, 10, 5, 3][case]
+        gt, res = [], []
+        for q in range(nq):
+            truth = rng.choice(500, k, replace=False)
+            for r, d in enumerate(truth):
+                gt.append((q, int(d), r, float(100 - r)))
+            if case == 2 and q == 3:          # a ground-truth row written twice counts twice in the denominator
+                gt.append((q, int(truth[0]), 0, 100.0))
+            if case == 1 and q % 7 == 0:      # queries the run did not answer
+                continue
+            n_ret = k if case != 2 else int(rng.integers(1, k + 1))   # fewer than k results
+            keep = rng.random(k) < [1.0, 0.7, 0.5, 0.34][case]
+            got = [int(d) if keep[i] else int(600 + rng.integers(0, 400)) for i, d in enumerate(truth)][:n_ret]
+            for r, d in enumerate(got):
+                res.append((q, d, r, float(50 - r)))
+        if case == 1:                         # and queries the ground truth does not hold
+            res += [(nq + 5, 1, 0, 1.0), (nq + 5, 2, 1, 0.5)]
+        for tag, rows in (("results", res), ("groundtruth", gt)):
+            with open(os.path.join(dst, "case%d_%s.tsv" % (case, tag)), "w") as f:
+                for q, d, r, sc in rows:
+                    f.write("%d\t%d\t%d\t%.6g\n" % (q, d, r, sc))
+        with contextlib.redirect_stdout(io.StringIO()):
+            expected["case%d" % case] = float(fn(os.path.join(dst, "case%d_results.tsv" % case),
+                                                 os.path.join(dst, "case%d_groundtruth.tsv" % case)))
+    json.dump({"note": "accuracy returned by the reference's compute_accuracy (scripts/run_experiments.py:287-309) "
+                       "for each (results, groundtruth) pair of this directory", "accuracy": expected},
+              open(os.path.join(dst, "expected.json"), "w"), indent=1)
+
+
 def main():
+    reference_accuracy_cases()
     reference_inner_format()
     os.makedirs(os.path.join(HERE, "toy"), exist_ok=True)
     strip(os.path.join(REF, "documents.jsonl"), os.path.join(HERE, "toy", "documents.jsonl"))

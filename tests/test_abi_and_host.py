@@ -246,6 +246,21 @@ def test_results_tsv_and_accuracy(tmp_path):
     assert accuracy(res, gt) == pytest.approx(2 / 4)
 
 
+def test_accuracy_against_values_the_reference_function_returned():
+    """`accuracy` over `read_results_tsv` equals what the reference's own compute_accuracy
+    (scripts/run_experiments.py:287-309, executed by tests/golden/make_fixtures.py in the build container)
+    returned for the same files: unanswered queries, queries without ground truth, fewer than k results,
+    a ground-truth row written twice."""
+    import json
+    from seismic_amd.index import accuracy, read_results_tsv
+    exp = json.load(open(os.path.join(GOLD, "accuracy", "expected.json")))["accuracy"]
+    assert len(exp) == 4
+    for case, want in exp.items():
+        got = accuracy(read_results_tsv(os.path.join(GOLD, "accuracy", case + "_results.tsv")),
+                       read_results_tsv(os.path.join(GOLD, "accuracy", case + "_groundtruth.tsv")))
+        assert got == want, (case, got, want)
+
+
 def test_inner_format_against_bytes_written_by_the_reference_converter(tmp_path):
     """tests/golden/toy_inner/* was written by the reference's scripts/convert_json_to_inner_format.py
     (tests/golden/make_fixtures.py runs it where /root/reference exists). The product must read those
