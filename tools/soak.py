@@ -29,6 +29,8 @@ for seed in range(LO, HI):
     finally:
         mp.undo()
 print("fuzz seeds %d..%d: %d failures in %.0f s" % (LO, HI - 1, len(bad), time.time() - t0), bad[:5], flush=True)
+if len(sys.argv) > 3 and sys.argv[3] == "fuzz-only":
+    sys.exit(0)
 # config 5 at full size vs the oracle
 dim, n_docs, nq = 200_000, 5_000_000, 200
 docs = _native.synth(n_docs, dim, 42, 0)
