@@ -408,32 +408,71 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
         run += hist[k];
       }
     }
-    // count per list, then fill (value key, doc) pairs
+    // count per list, then fill (value key, doc) pairs. The tie rule is defined on scan order (the first
+    // need_eq entries equal to the threshold are kept), so the documents are cut into contiguous chunks:
+    // a counting pass gives every chunk the number of threshold-equal entries before it, the selection
+    // pass then runs chunk-parallel, and so does the fill (a list's entries of chunk t precede those of t+1).
     std::vector<uint64_t> list_cnt(dim + 1, 0);
     std::vector<uint8_t> sel(nnz, 0);
-    {
-      uint64_t eq_seen = 0;
-      for (uint64_t i = 0; i < nnz; ++i) {  // sequential: the tie rule is defined on scan order
+    const int n_chunks = (int)std::max<uint64_t>(1, std::min<uint64_t>({(uint64_t)nt, 64ull, (1ull << 26) / std::max<uint64_t>(dim, 1), n_docs}));
+    std::vector<uint64_t> chunk_doc((size_t)n_chunks + 1, n_docs);
+    chunk_doc[0] = 0;
+    for (int t = 1; t < n_chunks; ++t) {   // chunk boundaries at documents, balanced by entries
+      const uint64_t want = nnz / (uint64_t)n_chunks * (uint64_t)t;
+      chunk_doc[(size_t)t] = (uint64_t)(std::lower_bound(offsets, offsets + n_docs + 1, want) - offsets);
+      if (chunk_doc[(size_t)t] > n_docs) chunk_doc[(size_t)t] = n_docs;
+      if (chunk_doc[(size_t)t] < chunk_doc[(size_t)t - 1]) chunk_doc[(size_t)t] = chunk_doc[(size_t)t - 1];
+    }
+    std::vector<uint64_t> eq_before((size_t)n_chunks + 1, 0);
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+    for (int t = 0; t < n_chunks; ++t) {
+      uint64_t eq = 0;
+      for (uint64_t i = offsets[chunk_doc[(size_t)t]]; i < offsets[chunk_doc[(size_t)t + 1]]; ++i)
+        eq += f16_desc_key(h.fwd_vals[i]) == thr_key;
+      eq_before[(size_t)t + 1] = eq;
+    }
+    for (int t = 0; t < n_chunks; ++t) eq_before[(size_t)t + 1] += eq_before[(size_t)t];
+    std::vector<uint32_t> chunk_cnt((size_t)n_chunks * dim, 0);   // entries kept per (chunk, list)
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+    for (int t = 0; t < n_chunks; ++t) {
+      uint64_t eq_seen = eq_before[(size_t)t];
+      uint32_t* my = chunk_cnt.data() + (size_t)t * dim;
+      for (uint64_t i = offsets[chunk_doc[(size_t)t]]; i < offsets[chunk_doc[(size_t)t + 1]]; ++i) {
         const uint32_t k = f16_desc_key(h.fwd_vals[i]);
         bool take = k < thr_key;
-        if (!take && k == thr_key && eq_seen < need_eq) {
-          take = true;
-          ++eq_seen;
-        }
+        if (!take && k == thr_key && eq_seen < need_eq) take = true;
+        eq_seen += k == thr_key;
         if (take) {
           sel[i] = 1;
-          list_cnt[wide[i] + 1]++;
+          my[wide[i]]++;
         }
       }
     }
-    for (uint64_t c = 0; c < dim; ++c) list_cnt[c + 1] += list_cnt[c];
+    for (uint64_t c = 0; c < dim; ++c) {
+      uint64_t n = 0;
+      for (int t = 0; t < n_chunks; ++t) n += chunk_cnt[(size_t)t * dim + c];
+      list_cnt[c + 1] = list_cnt[c] + n;
+    }
     const uint64_t n_sel = list_cnt[dim];
     std::vector<uint64_t> pairs(n_sel);  // (desc key << 32) | doc  -> ascending sort == (value desc, doc asc)
     {
-      std::vector<uint64_t> cur(list_cnt.begin(), list_cnt.end() - 1);
-      for (uint64_t doc = 0; doc < n_docs; ++doc)
-        for (uint64_t i = offsets[doc]; i < offsets[doc + 1]; ++i)
-          if (sel[i]) pairs[cur[wide[i]]++] = ((uint64_t)f16_desc_key(h.fwd_vals[i]) << 32) | doc;
+      // the cursor of chunk t in list c: the list's start + what the chunks before t keep there
+      std::vector<uint64_t> cur((size_t)n_chunks * dim);
+#pragma omp parallel for schedule(static) num_threads(nt)
+      for (int64_t c = 0; c < (int64_t)dim; ++c) {
+        uint64_t at = list_cnt[(size_t)c];
+        for (int t = 0; t < n_chunks; ++t) {
+          cur[(size_t)t * dim + (size_t)c] = at;
+          at += chunk_cnt[(size_t)t * dim + (size_t)c];
+        }
+      }
+#pragma omp parallel for schedule(static, 1) num_threads(nt)
+      for (int t = 0; t < n_chunks; ++t) {
+        uint64_t* my = cur.data() + (size_t)t * dim;
+        for (uint64_t doc = chunk_doc[(size_t)t]; doc < chunk_doc[(size_t)t + 1]; ++doc)
+          for (uint64_t i = offsets[doc]; i < offsets[doc + 1]; ++i)
+            if (sel[i]) pairs[my[wide[i]]++] = ((uint64_t)f16_desc_key(h.fwd_vals[i]) << 32) | doc;
+      }
     }
     sel.clear();
     sel.shrink_to_fit();

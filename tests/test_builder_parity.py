@@ -42,6 +42,29 @@ def test_builder_ties_and_duplicates():
     desc_equal(o.desc, p.desc)
 
 
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_pruning_ties_across_thread_chunks(seed):
+    """global_threshold_pruning keeps the FIRST entries (scan order) among those equal to the threshold
+    (src/inverted_index.rs:354-389). The product builder selects chunk-parallel; with values drawn from
+    five levels and few postings per list the threshold falls inside a large tie group that spans the
+    chunks - the index must equal the oracle's sequential builder for every thread count."""
+    rng = np.random.default_rng(seed)
+    dim, n_docs = int(rng.integers(20, 200)), int(rng.integers(300, 3000))
+    docs = []
+    for _ in range(n_docs):
+        n = int(rng.integers(0, min(dim, 30)))
+        cc = np.sort(rng.choice(dim, n, replace=False))
+        docs.append((cc.tolist(), rng.choice([0.25, 0.5, 0.75, 1.0, 1.5], n).tolist()))
+    off, c, v = orc.csr(docs)
+    npost = int(rng.integers(1, 40))
+    assert int(off[-1]) > dim * npost   # the pruning is active
+    for nt in (1, 3, 7, 0):
+        cfg = BuildConfig.defaults(n_postings=npost, centroid_fraction=0.3, summary_energy=0.5, max_fraction=2.0,
+                                   num_threads=nt)
+        built, want = _native.NativeIndex.build(2, dim, off, c, v, cfg), orc.OracleIndex(2, dim, off, c, v, cfg)
+        desc_equal(built.desc, want.desc)   # (the descriptors point into the two objects: both stay alive)
+
+
 def test_builder_rejects_bad_input():
     off = np.array([0, 2], np.uint64)
     with pytest.raises(_native.SeismicHipError):   # unsorted components
