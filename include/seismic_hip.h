@@ -232,6 +232,19 @@ sgpu_status sgpu_batch_search(sgpu_index* idx, const uint64_t* q_off,
                               const sgpu_search_params* params, float* out_scores,
                               uint64_t* out_doc_ids, uint32_t* out_n);
 
+/* Replaces: the sequential AQT loop of perf_inverted_index (src/bin/perf_inverted_index.rs:184-216), the
+ * loop behind the reference's published per-query latency: the nq queries of a CSR set are searched ONE
+ * AT A TIME, each through sgpu_search (host buffers in, results out, the call returns before the next
+ * one starts). *mean_us (may be NULL) = wall time of the loop / nq. breakdown_us (may be NULL) receives 8
+ * doubles, the mean microseconds per query the calling thread spent in each host-side phase:
+ *   [0] validation + launch plan  [1] staging into the pinned arena  [2] enqueue H2D
+ *   [3] launch configuration + kernel launch  [4] enqueue D2H  [5] waiting for the stream (the kernel
+ *   runs here)  [6] copying the rows out  [7] reserved. */
+sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps,
+                                   const float* vals, uint32_t nq, const sgpu_search_params* params,
+                                   float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n,
+                                   double* mean_us, double* breakdown_us);
+
 /* Device-resident variant (what bench.py times: inputs already in HBM when the
  * timed region starts; results stay in HBM until fetched). */
 sgpu_status sgpu_batch_create(sgpu_index* idx, const uint64_t* q_off,

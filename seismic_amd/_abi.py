@@ -2,7 +2,7 @@
 import ctypes as C
 
 SGPU_OK, SGPU_EINVAL, SGPU_EDEVICE, SGPU_ENOMEM, SGPU_EIO, SGPU_ELIMIT = range(6)
-ABI_VERSION = 3
+ABI_VERSION = 4
 SGPU_VAL_F16, SGPU_VAL_FIXEDU8 = 0, 1
 
 u8p = C.POINTER(C.c_uint8)

@@ -59,6 +59,8 @@ def lib():
         L.sgpu_search.argtypes = [vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp,
                                   C.POINTER(C.c_uint32)]
         L.sgpu_batch_search.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp, vp]
+        L.sgpu_search_sequential.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp, vp,
+                                             C.POINTER(C.c_double), vp]
         L.sgpu_batch_create.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.sgpu_batch_run.argtypes = [vp, vp, C.POINTER(SearchParams), C.c_int32, C.POINTER(LaunchStats)]
         L.sgpu_batch_run_counted.argtypes = [vp, vp, C.POINTER(SearchParams), C.POINTER(LaunchStats)]
@@ -220,6 +222,22 @@ class NativeIndex:
         check(lib().sgpu_batch_search(self.h, _p(q_off), _p(comps), _p(vals), nq, C.byref(p), _p(sc),
                                       _p(ids), _p(n)))
         return sc, ids, n[:nq]
+
+    def search_sequential(self, q_off, comps, vals, k, query_cut, heap_factor, first_sorted=False, n_knn=0):
+        """The reference's AQT loop (src/bin/perf_inverted_index.rs:184-216) natively: one sgpu_search per
+        query, timed around the loop. Returns (scores, ids, n, mean microseconds per query, the 8-entry
+        host-side phase breakdown in microseconds per query)."""
+        q_off, comps, vals = _csr(q_off, comps, vals)
+        nq = len(q_off) - 1
+        sc = np.zeros((nq, max(k, 1)), np.float32)
+        ids = np.zeros((nq, max(k, 1)), np.uint64)
+        n = np.zeros(max(nq, 1), np.uint32)
+        mean = C.c_double(0.0)
+        phases = np.zeros(8, np.float64)
+        p = params(k, query_cut, heap_factor, first_sorted, n_knn)
+        check(lib().sgpu_search_sequential(self.h, _p(q_off), _p(comps), _p(vals), nq, C.byref(p), _p(sc), _p(ids),
+                                           _p(n), C.byref(mean), _p(phases)))
+        return sc, ids, n[:nq], mean.value, phases
 
     def summary_distances(self, list_id, comps, vals):
         comps = np.ascontiguousarray(comps, np.uint32)

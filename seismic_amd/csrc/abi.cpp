@@ -1,5 +1,6 @@
 // abi.cpp — the extern "C" surface declared in include/seismic_hip.h.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 #include <new>
@@ -38,6 +39,7 @@ sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_
 sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list, const uint32_t* comps,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
 int device_count();
+double*& call_timing();
 const DeviceIndex* batch_replica(const sgpu_batch* b);
 sgpu_status device_index_set_knn(DeviceIndex* d, const std::vector<uint32_t>& knn, uint32_t knn_dim);
 sgpu_status build_knn_on_device(DeviceIndex* d, HostIndex& h, uint32_t nknn);
@@ -48,7 +50,7 @@ using namespace sgpu;
 extern "C" {
 
 const char* sgpu_last_error(void) { return last_error().c_str(); }
-uint32_t sgpu_abi_version(void) { return 3; }
+uint32_t sgpu_abi_version(void) { return 4; }
 
 sgpu_status sgpu_device_count(int32_t* n) {
   if (!n) return fail(SGPU_EINVAL, "null argument");
@@ -421,6 +423,37 @@ sgpu_status sgpu_search(sgpu_index* idx, const uint32_t* comps, const float* val
                         uint32_t* out_n) {
   const uint64_t q_off[2] = {0, nnz};
   return sgpu_batch_search(idx, q_off, comps, vals, 1, params, out_scores, out_doc_ids, out_n);
+}
+
+// The reference's AQT loop (src/bin/perf_inverted_index.rs:184-216): the queries of a set searched one
+// at a time, each through sgpu_search, timed around the whole loop.
+sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals,
+                                   uint32_t nq, const sgpu_search_params* params, float* out_scores,
+                                   uint64_t* out_doc_ids, uint32_t* out_n, double* mean_us, double* breakdown_us) {
+  if (!idx || !params || !q_off || !out_scores || !out_doc_ids || !out_n) return fail(SGPU_EINVAL, "null argument");
+  if (params->k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
+  double phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double*& slot = call_timing();
+  double* const saved = slot;
+  if (breakdown_us) slot = phases;
+  const uint32_t k = params->k;
+  sgpu_status st = SGPU_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t q = 0; q < nq && st == SGPU_OK; ++q) {
+    if (q_off[q + 1] < q_off[q] || q_off[q + 1] - q_off[q] > 0xffffffffull) {
+      st = fail(SGPU_EINVAL, "query offsets must be monotone (query %u)", q);
+      break;
+    }
+    st = sgpu_search(idx, comps ? comps + q_off[q] : nullptr, vals ? vals + q_off[q] : nullptr,
+                     (uint32_t)(q_off[q + 1] - q_off[q]), params, out_scores + (size_t)q * k,
+                     out_doc_ids + (size_t)q * k, out_n + q);
+  }
+  const double total = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  slot = saved;
+  if (mean_us) *mean_us = nq ? total / nq : 0.0;
+  if (breakdown_us)
+    for (int i = 0; i < 8; ++i) breakdown_us[i] = nq ? phases[i] / nq : 0.0;
+  return st;
 }
 
 sgpu_status sgpu_summary_distances(sgpu_index* idx, uint32_t list, const uint32_t* comps, const float* vals,

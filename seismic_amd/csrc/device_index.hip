@@ -2,9 +2,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -477,6 +479,53 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
   const char* v = std::getenv(name);
   if (!v || !*v) return dflt;
   return (uint32_t)std::strtoul(v, nullptr, 10);
+}
+
+// ---- host-side breakdown of a staged call (tools/latency_probe.py, sgpu_search_sequential) ----
+// A thread that sets call_timing() gets the wall time of every phase of its staged calls added up:
+// [0] validate + launch plan  [1] staging (pinned arena)  [2] enqueue H2D  [3] configure + kernel launch
+// [4] enqueue D2H  [5] wait for the stream  [6] copy the rows out
+double*& call_timing() {
+  static thread_local double* t = nullptr;
+  return t;
+}
+static inline double now_us() {
+  return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3;
+}
+struct PhaseClock {
+  double* acc;
+  double t;
+  PhaseClock() : acc(call_timing()), t(acc ? now_us() : 0.0) {}
+  inline void lap(int i) {
+    if (!acc) return;
+    const double n = now_us();
+    acc[i] += n - t;
+    t = n;
+  }
+};
+
+// How a call waits for its lane. hipStreamSynchronize parks the thread on an interrupt; waking it costs
+// what the host's idle state costs (tens to hundreds of microseconds on a quiet box: VERDICT r02 #8 saw
+// 192 us outside the kernel on the driver's box against 17 us on a busy one). A call small enough to be
+// latency-bound polls the stream instead (hipStreamQuery, no system call once the signal is mapped)
+// for at most SGPU_SPIN_US microseconds (default 2000) and only then parks. SGPU_WAIT=block|spin overrides.
+static hipError_t wait_lane(hipStream_t s, uint32_t nq) {
+  static const int mode = [] {
+    const char* v = std::getenv("SGPU_WAIT");
+    return (v && !std::strcmp(v, "block")) ? 0 : ((v && !std::strcmp(v, "spin")) ? 2 : 1);
+  }();
+  static const double spin_us = (double)env_u32("SGPU_SPIN_US", 2000);
+  if (mode == 2 || (mode == 1 && nq <= 256)) {
+    const double t0 = now_us();
+    for (;;) {
+      const hipError_t e = hipStreamQuery(s);
+      if (e == hipSuccess) return hipSuccess;
+      if (e != hipErrorNotReady) return e;
+      if (now_us() - t0 > spin_us) break;
+      __builtin_ia32_pause();
+    }
+  }
+  return hipStreamSynchronize(s);
 }
 
 void batch_free(sgpu_batch* b) {
@@ -1004,6 +1053,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   if (sp.k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
   if (sp.k > 1024) return fail(SGPU_ELIMIT, "k = %u exceeds the heap limit of 1024", sp.k);
   uint32_t max_nnz = 0;
+  PhaseClock pc;
   sgpu_status st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz, q_base);
   if (st != SGPU_OK) return st;
   HIP_TRY(hipSetDevice(d->device));
@@ -1052,6 +1102,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   }
   st = make_plan(d, q_off, comps, vals, nq, cut, &b->plans.back());
   if (st != SGPU_OK) return st;
+  pc.lap(0);
   uint8_t* hs = b->arena_host;
   std::memset(hs, 0, 16);
   uint32_t* h32 = (uint32_t*)(hs + o_off);
@@ -1071,7 +1122,9 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   b->out_scores = (float*)(b->arena_dev + r_sc);
   b->out_ids = (uint64_t*)(b->arena_dev + r_id);
   b->out_stats = nullptr;
+  pc.lap(1);
   HIP_TRY(hipMemcpyAsync(b->arena_dev, hs, in_bytes, hipMemcpyHostToDevice, lane->stream));
+  pc.lap(2);
   // from here on a failure waits for the stream: the lane (and its pinned arena) goes back to the pool
   hipError_t he = hipSuccess;
   {
@@ -1080,8 +1133,10 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     st = configure(d, lane, b, sp, MODE_SEARCH, &a);
     if (st == SGPU_OK) he = launch_search(a);
   }
+  pc.lap(3);
   if (st == SGPU_OK && he == hipSuccess)
     he = hipMemcpyAsync(hs + r_n, b->arena_dev + r_n, b->out_bytes, hipMemcpyDeviceToHost, lane->stream);
+  pc.lap(4);
   if (st != SGPU_OK || he != hipSuccess) {
     (void)hipStreamSynchronize(lane->stream);
     if (st == SGPU_OK) st = fail(SGPU_EDEVICE, "launch of the search failed: %s", hipGetErrorString(he));
@@ -1093,13 +1148,16 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
 // Waits for the lane's staged search and copies the rows out (nq x k slabs, row q padded past out_n[q]).
 sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_scores, uint64_t* out_ids, uint32_t* out_n) {
   HIP_TRY(hipSetDevice(d->device));
-  HIP_TRY(hipStreamSynchronize(lane->stream));
+  PhaseClock pc;
+  HIP_TRY(wait_lane(lane->stream, b ? b->nq : 0));
+  pc.lap(5);
   if (!b || b->nq == 0) return SGPU_OK;
   const size_t nq = b->nq, k = b->k_max;
   const uint8_t* r = b->arena_host + b->out_off;
   std::memcpy(out_n, r, nq * 4);
   std::memcpy(out_scores, r + al16(nq * 4), nq * k * 4);
   std::memcpy(out_ids, r + al16(nq * 4) + al16(nq * k * 4), nq * k * 8);
+  pc.lap(6);
   return SGPU_OK;
 }
 

@@ -162,7 +162,9 @@ def search(desc, comps, vals, k, query_cut, heap_factor, first_sorted=False, ord
 
 
 def batch_search(desc, q_off, comps, vals, k, query_cut, heap_factor, first_sorted=False,
-                 order=ORDER_LANES16, num_threads=0, n_knn=0):
+                 order=ORDER_LANES16, num_threads=0, n_knn=0, tuned=False):
+    """tuned=True: the AVX2/F16C + hash-set variant of the same algorithm (bit-identical results; what
+    bench.py times as cpu_baseline)."""
     q_off = np.ascontiguousarray(q_off, np.uint64)
     comps = np.ascontiguousarray(comps, np.uint32)
     vals = np.ascontiguousarray(vals, np.float32)
@@ -174,9 +176,9 @@ def batch_search(desc, q_off, comps, vals, k, query_cut, heap_factor, first_sort
     secs = C.c_double(0)
     used = C.c_uint32(0)
     p = params(k, query_cut, heap_factor, first_sorted, n_knn)
-    rc = lib().orc_batch_search(C.byref(desc), _p(q_off), _p(comps), _p(vals), nq, C.byref(p), order,
-                                num_threads, _p(sc), _p(ids), _p(n), C.byref(st), C.byref(secs),
-                                C.byref(used))
+    fn = lib().orc_batch_search_tuned if tuned else lib().orc_batch_search
+    rc = fn(C.byref(desc), _p(q_off), _p(comps), _p(vals), nq, C.byref(p), order,
+            num_threads, _p(sc), _p(ids), _p(n), C.byref(st), C.byref(secs), C.byref(used))
     if rc:
         raise ValueError("oracle rejected the batch (rc=%d)" % rc)
     return sc, ids, n, st.as_dict(), secs.value, used.value
@@ -213,6 +215,14 @@ def quantize(values):
     mn, qt = C.c_float(0), C.c_float(0)
     lib().orc_quantize(_p(v), len(v), C.byref(mn), C.byref(qt), _p(codes))
     return mn.value, qt.value, codes
+
+
+def score_doc_tuned(desc, doc, comps, vals):
+    comps = np.ascontiguousarray(comps, np.uint32)
+    vals = np.ascontiguousarray(vals, np.float32)
+    lib().orc_score_doc_tuned.restype = C.c_float
+    lib().orc_score_doc_tuned.argtypes = [C.POINTER(IndexDesc), C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
+    return float(lib().orc_score_doc_tuned(C.byref(desc), doc, _p(comps), _p(vals), len(comps)))
 
 
 def score_doc(desc, doc, comps, vals, order=ORDER_LANES16):

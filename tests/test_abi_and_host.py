@@ -25,7 +25,7 @@ def test_every_declared_symbol_is_exported():
     L = ctypes.CDLL(_native.LIB_PATH)
     missing = [n for n in sorted(names) if not hasattr(L, n)]
     assert not missing, missing
-    assert L.sgpu_abi_version() == 3
+    assert L.sgpu_abi_version() == 4
 
 
 def test_struct_layouts_match_header_sizes():

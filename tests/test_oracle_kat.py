@@ -240,3 +240,44 @@ def test_lossy_summary_distances_against_a_straight_line_loop():
                     acc[blk] = f32(acc[blk] + f32(deq * v))
             got = orc.summary_distances(ix.desc, int(l), qc, qv)
             assert np.array_equal(np.asarray(acc, np.float32).view(np.uint32), got.view(np.uint32)), (t, l)
+
+
+# ---- the tuned CPU path (cpu_baseline) is the restatement, bit for bit -------------------------
+@pytest.mark.parametrize("comp_width,fixedu8", [(2, False), (4, False), (2, True)])
+def test_tuned_cpu_path_is_bit_identical_to_the_restatement(comp_width, fixedu8):
+    """bench.py times orc_batch_search_tuned (AVX2 + F16C scorer, hash-set visited set, pinned threads) as
+    cpu_baseline; it must return what the plain restatement returns: same ids, same score bits, same work
+    counters - for every document length class (tails of 1..7 elements, > 128, > 256 elements), both
+    value types, both component widths, sorted first list, kNN refinement, several thread counts."""
+    from util import random_dataset, random_queries
+    dim = 700 if comp_width == 2 else 70000
+    off, comps, vals = random_dataset(11 + comp_width, 3000, dim, nnz_lo=1, nnz_hi=300, empty_every=97)
+    vals = vals.copy()
+    vals[::13] = 0.0            # stored zeros
+    ix = orc.OracleIndex(comp_width, dim, off, comps, vals,
+                         BuildConfig.defaults(n_postings=400, centroid_fraction=0.2, summary_energy=0.5, max_fraction=6.0))
+    if fixedu8:
+        ix = ix.convert_fixedu8()
+    q_off, qc, qv = random_queries(5, 60, dim, 3, 60)
+    qv = qv.copy()
+    qv[::7] *= -1.0             # negative weights
+    # the scorer alone, document by document
+    for doc in list(range(0, 3000, 37)) + [96]:
+        for q in (0, 7, 31):
+            c, v = qc[int(q_off[q]):int(q_off[q + 1])], qv[int(q_off[q]):int(q_off[q + 1])]
+            a = np.float32(orc.score_doc(ix.desc, doc, c, v)).view(np.uint32)
+            b = np.float32(orc.score_doc_tuned(ix.desc, doc, c, v)).view(np.uint32)
+            assert a == b, (doc, q)
+    knn = orc.knn_build(ix.desc, 4) if not fixedu8 else None
+    try:
+        if knn is not None:
+            orc.knn_attach(knn, 4)
+        for k, cut, hf, srt, nk in ((10, 4, 1.0, False, 0), (100, 10, 0.7, True, 0), (5, 3, 0.9, True, 2 if knn is not None else 0)):
+            ref = orc.batch_search(ix.desc, q_off, qc, qv, k, cut, hf, srt, num_threads=1, n_knn=nk)
+            for nt in (1, 3):
+                got = orc.batch_search(ix.desc, q_off, qc, qv, k, cut, hf, srt, num_threads=nt, n_knn=nk, tuned=True)
+                assert np.array_equal(ref[2], got[2]) and np.array_equal(ref[1], got[1])
+                assert np.array_equal(ref[0].view(np.uint32), got[0].view(np.uint32))
+                assert ref[3] == got[3]          # work counters / algorithmic bytes
+    finally:
+        orc.knn_attach(None, 0)
