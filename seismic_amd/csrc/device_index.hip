@@ -57,6 +57,8 @@ struct Lane {
   sgpu_batch* scratch = nullptr;   // pool lanes: the recycled device batch (no allocation per call)
   uint32_t* bitmaps = nullptr;     // visited bitmaps of the counted pass, one per resident workgroup
   uint32_t bitmaps_slots = 0;
+  uint8_t* coop = nullptr;         // board of the cooperative kernel variant (CoopView), all zero between launches
+  size_t coop_bytes = 0;
   std::vector<hipEvent_t> ev0, ev1;   // timing of enqueued launches
   int ev_pending = 0;
   double sum_ms = 0;
@@ -112,6 +114,7 @@ static void lane_free(Lane* l) {
   if (l->scratch) batch_free(l->scratch);
   if (l->queue) (void)hipFree(l->queue);
   if (l->bitmaps) (void)hipFree(l->bitmaps);
+  if (l->coop) (void)hipFree(l->coop);
   for (hipEvent_t e : l->ev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : l->ev1) (void)hipEventDestroy(e);
   if (l->stream) (void)hipStreamDestroy(l->stream);
@@ -163,6 +166,7 @@ static sgpu_status dev_copy(DeviceIndex* d, const T* src, size_t n, const T** ou
   if (hipMalloc(&p, bytes) != hipSuccess) return fail(SGPU_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
   d->allocs.push_back(Alloc{p, bytes, (size_t)((const char*)out - (const char*)d)});
   d->bytes += bytes;
+  if (std::getenv("SGPU_DEBUG_ALLOC")) std::fprintf(stderr, "sgpu alloc: field@%zu %p..%p\n", (size_t)((const char*)out - (const char*)d), p, (void*)((char*)p + bytes));
   if (n) HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
   *out = (const T*)p;
   return SGPU_OK;
@@ -290,6 +294,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       d->allocs.push_back(Alloc{fp, fbytes, (size_t)((const char*)&d->view.fwd - (const char*)d)});
       d->bytes += fbytes;
       d->view.fwd = (const uint8_t*)fp;
+      if (std::getenv("SGPU_DEBUG_ALLOC")) std::fprintf(stderr, "sgpu alloc: fwd %p..%p\n", fp, (void*)((char*)fp + fbytes));
       HIP_TRY(hipMemcpy(fp, fwd.data(), fwd.size(), hipMemcpyHostToDevice));
     }
     fwd.clear();
@@ -894,10 +899,20 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     a->qb.q_seed = b->q_order + b->nq;
   }
   a->qb.out_stats = mode != MODE_DOTS ? b->out_stats : nullptr;   // (null for staged batches: no work counters)
+  // cooperative variant wanted? (decided before the occupancy query: it is its own kernel symbol)
+  a->coop = CoopView{};
+  {
+    const char* cm = std::getenv("SGPU_COOP");
+    const bool force = cm && !std::strcmp(cm, "force");
+    const bool off = cm && !std::strcmp(cm, "0");
+    const uint32_t max_nq = env_u32("SGPU_COOP_MAX_NQ", 8 * d->n_cu);
+    if (!off && !a->counted && mode == MODE_SEARCH && a->lds_bytes - a->L.uni >= 4096 && (force || b->nq <= max_nq))
+      a->coop.enabled = force ? 2u : 1u;
+  }
   // occupancy of this kernel variant at this LDS size: queried once, then remembered
   int per_cu = 0;
   {
-    const uint64_t key = ((uint64_t)a->comp_width << 56) | ((uint64_t)a->counted << 55) | ((uint64_t)a->value_type << 54) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
+    const uint64_t key = ((uint64_t)(a->coop.enabled != 0) << 58) | ((uint64_t)a->comp_width << 56) | ((uint64_t)a->counted << 55) | ((uint64_t)a->value_type << 54) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
                          ((uint64_t)heap_variant(a->p.k) << 28) | (uint64_t)(a->lds_bytes >> 4);
     auto it = d->occupancy.find(key);
     if (it == d->occupancy.end()) {
@@ -911,7 +926,50 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   const uint32_t cap = env_u32("SGPU_WG_PER_CU", 0);
   if (cap && (uint32_t)per_cu > cap) per_cu = (int)cap;
   uint32_t grid = d->n_cu * (uint32_t)per_cu;
-  grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
+  // Cooperative variant (small launches and their tails; DESIGN.md "Cooperative mode"): every slot of the
+  // chip is launched, workgroups without a query help the ones that own one. SGPU_COOP=0 disables it,
+  // SGPU_COOP=force enables it for any launch and lets owners go wide without waiting for idle workgroups
+  // (the tests: the whole protocol then runs inside big batches too).
+  {
+    const bool force = a->coop.enabled == 2;
+    const uint64_t uni_bytes = a->lds_bytes - a->L.uni;
+    if (a->coop.enabled && grid > 512) a->coop.enabled = 0;   // (the open-round bitmap has 512 bits)
+    if (a->coop.enabled) {
+      CoopView& c = a->coop;
+      c.max_pos = std::min<uint32_t>(65535u, std::max<uint32_t>(a->L.dots_cap, 1u));
+      c.max_cand = (uint32_t)std::min<uint64_t>(env_u32("SGPU_COOP_MAX_CAND", 1024), uni_bytes / 20);
+      c.chunk = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(env_u32("SGPU_COOP_CHUNK", 128), 16u), uni_bytes / 16);
+      c.min_items = env_u32("SGPU_COOP_MIN_ITEMS", force ? 64 : 256);
+      c.idle_min = env_u32("SGPU_COOP_IDLE_MIN", force ? 0 : std::max<uint32_t>(8, grid / 2));
+      c.enabled = 1u | (env_u32("SGPU_COOP_DEBUG", 0) << 8);
+      const size_t o_slots = 128, o_pos = o_slots + (size_t)grid * kCoopSlotWords * 8,
+                   o_cand = o_pos + (size_t)grid * c.max_pos * 8, total = o_cand + (size_t)grid * c.max_cand * 16;
+      if (lane->coop_bytes < total) {
+        if (lane->coop) {
+          HIP_TRY(hipStreamSynchronize(lane->stream));
+          (void)hipFree(lane->coop);
+        }
+        lane->coop = nullptr;
+        lane->coop_bytes = 0;
+        if (hipMalloc((void**)&lane->coop, total) != hipSuccess)
+          return fail(SGPU_ENOMEM, "hipMalloc of the %zu-byte cooperative board failed", total);
+        lane->coop_bytes = total;
+        HIP_TRY(hipMemsetAsync(lane->coop, 0, total, lane->stream));
+      } else if (lane->coop_bytes && env_u32("SGPU_COOP_RESET", 0)) {   // (debugging aid: do not trust the kernel's own clean-up)
+        HIP_TRY(hipMemsetAsync(lane->coop, 0, o_pos, lane->stream));
+      }
+      if (env_u32("SGPU_DEBUG", 0))
+        std::fprintf(stderr, "sgpu coop: board %p..%p slots@%zu pos@%zu cand@%zu grid %u max_pos %u max_cand %u chunk %u min_items %u idle_min %u\n",
+                     (void*)lane->coop, (void*)(lane->coop + total), o_slots, o_pos, o_cand, grid, c.max_pos, c.max_cand, c.chunk,
+                     c.min_items, c.idle_min);
+      c.open = (uint64_t*)lane->coop;
+      c.counters = (uint32_t*)(lane->coop + 64);
+      c.slots = (uint64_t*)(lane->coop + o_slots);
+      c.pos_pub = (uint64_t*)(lane->coop + o_pos);
+      c.cands = (uint64_t*)(lane->coop + o_cand);
+    }
+  }
+  if (!a->coop.enabled) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
   a->grid = grid;
   // visited bitmaps: one per resident workgroup (counted pass)
   a->bitmaps = nullptr;
@@ -945,6 +1003,17 @@ static void drain_events(Lane* l) {   // stream must be idle
     }
   }
   l->ev_pending = 0;
+}
+
+// SGPU_COOP_CHECK=1 (the test suite sets it): after a lane's work is waited for, read the cooperative
+// board's sticky error word - a bounded device-side wait that gave up - and fail the call loudly.
+static sgpu_status coop_check(Lane* lane) {
+  static const bool on = env_u32("SGPU_COOP_CHECK", 0) != 0;
+  if (!on || !lane->coop) return SGPU_OK;
+  uint32_t flag = 0;
+  HIP_TRY(hipMemcpy(&flag, lane->coop + 64 + 12, 4, hipMemcpyDeviceToHost));
+  if (flag) return fail(SGPU_EDEVICE, "cooperative search kernel: protocol wait gave up (code %u)", flag);
+  return SGPU_OK;
 }
 
 // Enqueues one pass on `lane` (the index's main lane when null).
@@ -1030,7 +1099,7 @@ sgpu_status batch_fetch(DeviceIndex* d, Lane* lane, sgpu_batch* b, uint32_t k, f
   }
   HIP_TRY(hipMemcpyAsync(out_n, b->out_n, (size_t)b->nq * 4, hipMemcpyDeviceToHost, lane->stream));
   HIP_TRY(hipStreamSynchronize(lane->stream));
-  return SGPU_OK;
+  return coop_check(lane);
 }
 
 sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out) {
@@ -1084,6 +1153,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
       return fail(SGPU_ENOMEM, "allocation of a %zu-byte staging arena failed", b->arena_cap);
     }
     *slot = b;
+    if (std::getenv("SGPU_DEBUG_ALLOC")) std::fprintf(stderr, "sgpu alloc: arena %p..%p\n", (void*)b->arena_dev, (void*)(b->arena_dev + b->arena_cap));
   }
   b->nq = nq;
   b->k_max = k;
@@ -1151,6 +1221,10 @@ sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_
   PhaseClock pc;
   HIP_TRY(wait_lane(lane->stream, b ? b->nq : 0));
   pc.lap(5);
+  {
+    const sgpu_status cs = coop_check(lane);
+    if (cs != SGPU_OK) return cs;
+  }
   if (!b || b->nq == 0) return SGPU_OK;
   const size_t nq = b->nq, k = b->k_max;
   const uint8_t* r = b->arena_host + b->out_off;

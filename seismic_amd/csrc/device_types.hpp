@@ -67,7 +67,34 @@ SGPU_HD inline uint32_t hash_mult(uint32_t seed) {
 }
 SGPU_HD inline uint32_t hash_slot(uint32_t c, uint32_t mult) { return (c ^ ((c >> 15) * mult)) & (kHashSlots - 1); }
 enum { STATS_WORDS = 24 };
-enum { kStateWords = 144 };   // per-workgroup state words in LDS (ST_* in search_kernel.hip)   // per-query stats: 8 work counters + 12 phase clocks (>>4) + slot + pad
+enum { kStateWords = 160 };   // per-workgroup state words in LDS (ST_* in search_kernel.hip)   // per-query stats: 8 work counters + 12 phase clocks (>>4) + slot + pad
+
+// Cooperative mode (small launches, launch tails): workgroups that find the query queue empty do not
+// exit but HELP the workgroups that still own a query. An owner whose heap is full publishes one WIDE
+// ROUND - every remaining block of its list group in traversal order, as {summary dot, global block id}
+// records - on a board in HBM; helpers (and the owner itself) claim chunks of positions, apply the skip
+// test against the round's starting threshold, score the documents of the surviving blocks and append the
+// items that beat that threshold to the owner's candidate list; the owner then replays the candidates in
+// traversal order with the reference's sequential rules (live threshold, block decided at its first
+// item, heap membership for re-encountered documents). Scores do not depend on who computes them and a
+// staler threshold only admits more blocks, so the result is the reference's, bit for bit.
+// All shared words are written and read with agent-scope (sc1) accesses; see search_kernel.inc.
+struct CoopView {
+  uint64_t* open;       // [8] bit s: slot s has an open round with unclaimed positions (one 64-byte line)
+  uint32_t* counters;   // [0] idle workgroups [1] finished queries [2] exited workgroups [3] sticky protocol-error flag
+                        //   (a bounded wait gave up; checked by the host after every cooperative launch of a checked lane)
+  uint64_t* slots;      // per owner slot (blockIdx.x), kCoopSlotWords u64: [0] claim = seq:20 | end:22 | next:22
+                        //   [1] done:32 | -   [2] n_cand:32 | -   [3] query:32 | thr0:32   [4] cut:32 | seq:32
+  uint64_t* pos_pub;    // [slots x max_pos] {dot bits : 32 | global block id : 32}, traversal order
+  uint64_t* cands;      // [slots x max_cand x 2] {score bits:32 | key:32 (pos << 16 | posting in block)}, {bdot bits:32 | doc:32}
+  uint32_t max_pos;     // positions per slot (<= 65535)
+  uint32_t max_cand;    // candidates per round the owner can sort in LDS; more = the owner falls back to local rounds
+  uint32_t chunk;       // positions per claim
+  uint32_t min_items;   // local items replayed before a query may go wide (a useful threshold first)
+  uint32_t idle_min;    // idle workgroups needed before an owner goes wide (0 = always, used by the tests)
+  uint32_t enabled;
+};
+enum { kCoopSlotWords = 8 };
 
 struct KParams {
   uint32_t k, query_cut;
@@ -97,6 +124,7 @@ struct LaunchArgs {
   LdsLayout L;
   uint32_t* queue;
   uint32_t* bitmaps;
+  CoopView coop;    // enabled == 0: the plain kernel variants
   uint32_t comp_width, grid, block, lds_bytes;
   uint32_t lookup;  // LK_*: layout of the query lookup table in LDS
   uint32_t value_type; // SGPU_VAL_*: how the records store document values

@@ -9,5 +9,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# every cooperative launch of the suite is checked for a device-side wait that gave up (device_index.hip: coop_check)
+os.environ.setdefault("SGPU_COOP_CHECK", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
