@@ -40,6 +40,7 @@ sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
 int device_count();
 double*& call_timing();
+uint32_t coop_trace_dump(DeviceIndex* d, uint64_t* out, uint32_t cap);
 const DeviceIndex* batch_replica(const sgpu_batch* b);
 sgpu_status device_index_set_knn(DeviceIndex* d, const std::vector<uint32_t>& knn, uint32_t knn_dim);
 sgpu_status build_knn_on_device(DeviceIndex* d, HostIndex& h, uint32_t nknn);
@@ -454,6 +455,11 @@ sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const
   if (breakdown_us)
     for (int i = 0; i < 8; ++i) breakdown_us[i] = nq ? phases[i] / nq : 0.0;
   return st;
+}
+
+// (not part of the boundary: the timeline of a cooperative launch, for tools/coop_trace.py on a trace build)
+uint32_t sgpu_debug_coop_trace(sgpu_index* idx, uint64_t* out, uint32_t cap) {
+  return idx ? coop_trace_dump(idx->dev, out, cap) : 0;
 }
 
 sgpu_status sgpu_summary_distances(sgpu_index* idx, uint32_t list, const uint32_t* comps, const float* vals,

@@ -58,7 +58,8 @@ struct Lane {
   uint32_t* bitmaps = nullptr;     // visited bitmaps of the counted pass, one per resident workgroup
   uint32_t bitmaps_slots = 0;
   uint8_t* coop = nullptr;         // board of the cooperative kernel variant (CoopView), all zero between launches
-  size_t coop_bytes = 0;
+  size_t coop_bytes = 0, coop_trace_off = 0;
+  uint32_t coop_trace_n = 0;
   std::vector<hipEvent_t> ev0, ev1;   // timing of enqueued launches
   int ev_pending = 0;
   double sum_ms = 0;
@@ -905,7 +906,10 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     const char* cm = std::getenv("SGPU_COOP");
     const bool force = cm && !std::strcmp(cm, "force");
     const bool off = cm && !std::strcmp(cm, "0");
-    const uint32_t max_nq = env_u32("SGPU_COOP_MAX_NQ", 8 * d->n_cu);
+    // (measured r03, 8.8M documents: 1 query 133 vs 200 us, 8: 147 vs 297, 64: 316 vs 412, 256: 431 vs 486;
+    // from ~1000 queries per launch on the variant's own cost - 6 % slower rounds, idle workgroups kept
+    // resident - outweighs what its tail help returns: 780 vs 742 us)
+    const uint32_t max_nq = env_u32("SGPU_COOP_MAX_NQ", d->n_cu);
     if (!off && !a->counted && mode == MODE_SEARCH && a->lds_bytes - a->L.uni >= 4096 && (force || b->nq <= max_nq))
       a->coop.enabled = force ? 2u : 1u;
   }
@@ -937,13 +941,19 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     if (a->coop.enabled) {
       CoopView& c = a->coop;
       c.max_pos = std::min<uint32_t>(65535u, std::max<uint32_t>(a->L.dots_cap, 1u));
-      c.max_cand = (uint32_t)std::min<uint64_t>(env_u32("SGPU_COOP_MAX_CAND", 1024), uni_bytes / 20);
-      c.chunk = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(env_u32("SGPU_COOP_CHUNK", 128), 16u), uni_bytes / 16);
-      c.min_items = env_u32("SGPU_COOP_MIN_ITEMS", force ? 64 : 256);
-      c.idle_min = env_u32("SGPU_COOP_IDLE_MIN", force ? 0 : std::max<uint32_t>(8, grid / 2));
+      c.max_cand = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(env_u32("SGPU_COOP_MAX_CAND", 1024), NT), uni_bytes / 20);
+      c.chunk = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(std::max<uint32_t>(env_u32("SGPU_COOP_CHUNK", 128), 1u), std::min<uint32_t>(NT, 1023u)),
+                                             uni_bytes / 16);
+      c.chunk_min = std::min<uint32_t>(c.chunk, std::max<uint32_t>(env_u32("SGPU_COOP_CHUNK_MIN", 4), 1u));
+      c.min_items = env_u32("SGPU_COOP_MIN_ITEMS", 64);
+      c.first_reach = std::max<uint32_t>(1, env_u32("SGPU_COOP_FIRST_REACH", 384));
+      c.idle_min = env_u32("SGPU_COOP_IDLE_MIN", force ? 0 : 8);
+      c.idle_ratio = env_u32("SGPU_COOP_IDLE_RATIO", force ? 0 : 8);
+      c.poll_sleep = std::max<uint32_t>(1, env_u32("SGPU_COOP_POLL", 2));
       c.enabled = 1u | (env_u32("SGPU_COOP_DEBUG", 0) << 8);
       const size_t o_slots = 128, o_pos = o_slots + (size_t)grid * kCoopSlotWords * 8,
-                   o_cand = o_pos + (size_t)grid * c.max_pos * 8, total = o_cand + (size_t)grid * c.max_cand * 16;
+                   o_cand = o_pos + (size_t)grid * c.max_pos * 8, o_trace = o_cand + (size_t)grid * c.max_cand * 16,
+                   total = o_trace + (size_t)grid * 16 * 8;
       if (lane->coop_bytes < total) {
         if (lane->coop) {
           HIP_TRY(hipStreamSynchronize(lane->stream));
@@ -959,16 +969,26 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
         HIP_TRY(hipMemsetAsync(lane->coop, 0, o_pos, lane->stream));
       }
       if (env_u32("SGPU_DEBUG", 0))
-        std::fprintf(stderr, "sgpu coop: board %p..%p slots@%zu pos@%zu cand@%zu grid %u max_pos %u max_cand %u chunk %u min_items %u idle_min %u\n",
-                     (void*)lane->coop, (void*)(lane->coop + total), o_slots, o_pos, o_cand, grid, c.max_pos, c.max_cand, c.chunk,
-                     c.min_items, c.idle_min);
+        std::fprintf(stderr, "sgpu coop: board %p..%p slots@%zu pos@%zu cand@%zu grid %u max_pos %u max_cand %u chunk %u..%u min_items %u idle_min %u idle_ratio %u\n",
+                     (void*)lane->coop, (void*)(lane->coop + total), o_slots, o_pos, o_cand, grid, c.max_pos, c.max_cand, c.chunk_min, c.chunk,
+                     c.min_items, c.idle_min, c.idle_ratio);
       c.open = (uint64_t*)lane->coop;
       c.counters = (uint32_t*)(lane->coop + 64);
       c.slots = (uint64_t*)(lane->coop + o_slots);
       c.pos_pub = (uint64_t*)(lane->coop + o_pos);
       c.cands = (uint64_t*)(lane->coop + o_cand);
+      c.trace = nullptr;
+      if (env_u32("SGPU_COOP_TRACE", 0)) {   // (trace builds) the timeline of this launch: zeroed here, dumped by coop_trace_dump
+        c.trace = (uint64_t*)(lane->coop + o_trace);
+        HIP_TRY(hipMemsetAsync(lane->coop + o_trace, 0, (size_t)grid * 16 * 8, lane->stream));
+        lane->coop_trace_off = o_trace;
+        lane->coop_trace_n = grid * 16;
+      }
     }
   }
+  // latency-bound launches bootstrap the threshold with ONE local round before they go wide
+  if (a->coop.enabled && b->nq <= d->n_cu && !std::getenv("SGPU_ITEMS_INIT"))
+    a->p.items_init = std::min<uint32_t>(a->p.items_max, std::max<uint32_t>(1, env_u32("SGPU_COOP_ITEMS_INIT", 64)));
   if (!a->coop.enabled) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
   a->grid = grid;
   // visited bitmaps: one per resident workgroup (counted pass)
@@ -1108,6 +1128,25 @@ sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out) {
   HIP_TRY(hipStreamSynchronize(d->main.stream));
   if (b->nq) HIP_TRY(hipMemcpy(out, b->out_stats, (size_t)b->nq * STATS_WORDS * 4, hipMemcpyDeviceToHost));
   return SGPU_OK;
+}
+
+// (trace builds) the event times of the last traced cooperative launch of any pool lane of replica d
+uint32_t coop_trace_dump(DeviceIndex* d, uint64_t* out, uint32_t cap) {
+  if (!d) return 0;
+  (void)hipSetDevice(d->device);
+  Lane* lanes[DeviceIndex::kPool + 1];
+  int nl = 0;
+  lanes[nl++] = &d->main;
+  for (Lane& l : d->pool) lanes[nl++] = &l;
+  for (int i = 0; i < nl; ++i) {
+    Lane* l = lanes[i];
+    if (!l->coop || !l->coop_trace_n) continue;
+    (void)hipStreamSynchronize(l->stream);
+    const uint32_t n = std::min<uint32_t>(cap, l->coop_trace_n);
+    if (hipMemcpy(out, l->coop + l->coop_trace_off, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return n;
+  }
+  return 0;
 }
 
 // ---- staged batches: the lean path behind sgpu_search / sgpu_batch_search ----------------------

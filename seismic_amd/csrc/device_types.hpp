@@ -89,10 +89,15 @@ struct CoopView {
   uint64_t* cands;      // [slots x max_cand x 2] {score bits:32 | key:32 (pos << 16 | posting in block)}, {bdot bits:32 | doc:32}
   uint32_t max_pos;     // positions per slot (<= 65535)
   uint32_t max_cand;    // candidates per round the owner can sort in LDS; more = the owner falls back to local rounds
-  uint32_t chunk;       // positions per claim
+  uint32_t chunk;       // most positions per claim (sizes the helpers' LDS tables; <= the workgroup size)
+  uint32_t chunk_min;   // fewest positions per claim (the owner picks the round's figure in between)
+  uint32_t idle_ratio;  // an owner goes wide only while idle workgroups >= idle_ratio x workgroups still owning a query
   uint32_t min_items;   // local items replayed before a query may go wide (a useful threshold first)
+  uint32_t first_reach; // positions of a query's first wide round (the following one takes the rest)
   uint32_t idle_min;    // idle workgroups needed before an owner goes wide (0 = always, used by the tests)
+  uint32_t poll_sleep;  // idle workgroups look at the board every poll_sleep x ~0.45 us
   uint32_t enabled;
+  uint64_t* trace;      // [slots x 16] event times (trace builds: -DSGPU_COOP_TRACE), else null
 };
 enum { kCoopSlotWords = 8 };
 

@@ -30,13 +30,14 @@ def main():
             n_postings=2000, centroid_fraction=0.2, summary_energy=0.5, max_fraction=6.0, use_device=1))
         ix.save(path)
     ix.upload(0)
-    q_off, qc, qv = _native.synth(1000, 30000, 43, 1, docs)
+    NQ = 5000
+    q_off, qc, qv = _native.synth(NQ, 30000, 43, 1, docs)
     env = {k: v for k, v in os.environ.items() if k.startswith("SGPU_")}
     out = {"n_docs": n, "env": env, "passes": {}}
-    for nq in (1, 8, 64, 256, 1000):
-        reps = 200 if nq == 1 else 20
+    for nq in (1, 8, 64, 256, 1000, 1250):
+        reps = 200 if nq == 1 else (20 if nq < 1000 else 4)
         batches = []
-        for r in range(min(reps, 1000 // nq)):
+        for r in range(min(reps, NQ // nq)):
             lo, hi = r * nq, (r + 1) * nq
             batches.append(_native.DeviceBatch(ix, q_off[lo:hi + 1] - q_off[lo], qc[q_off[lo]:q_off[hi]], qv[q_off[lo]:q_off[hi]], 10))
         for b in batches[:3]:
