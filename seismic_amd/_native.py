@@ -212,12 +212,19 @@ class NativeIndex:
                                 C.byref(n)))
         return sc[: n.value].copy(), ids[: n.value].copy()
 
-    def batch_search(self, q_off, comps, vals, k, query_cut, heap_factor, first_sorted=False, n_knn=0):
+    def batch_search(self, q_off, comps, vals, k, query_cut, heap_factor, first_sorted=False, n_knn=0, out=None):
+        """out: optional (scores f32 [nq, k], ids u64 [nq, k], n u32 [nq]) to receive the rows (no allocation per call)."""
         q_off, comps, vals = _csr(q_off, comps, vals)
         nq = len(q_off) - 1
-        sc = np.zeros((nq, max(k, 1)), np.float32)
-        ids = np.zeros((nq, max(k, 1)), np.uint64)
-        n = np.zeros(max(nq, 1), np.uint32)
+        if out is not None:
+            sc, ids, n = out
+            assert sc.shape == (nq, k) and ids.shape == (nq, k) and len(n) >= nq
+            assert sc.dtype == np.float32 and ids.dtype == np.uint64 and n.dtype == np.uint32
+            assert sc.flags.c_contiguous and ids.flags.c_contiguous and n.flags.c_contiguous
+        else:
+            sc = np.zeros((nq, max(k, 1)), np.float32)
+            ids = np.zeros((nq, max(k, 1)), np.uint64)
+            n = np.zeros(max(nq, 1), np.uint32)
         p = params(k, query_cut, heap_factor, first_sorted, n_knn)
         check(lib().sgpu_batch_search(self.h, _p(q_off), _p(comps), _p(vals), nq, C.byref(p), _p(sc),
                                       _p(ids), _p(n)))

@@ -15,6 +15,7 @@
 // unspecified are documented in DESIGN.md ("Restated choices") and are the same
 // as the oracle's, so both builders produce the identical index.
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -342,10 +343,12 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
   const int nt = 1;
 #endif
   const bool debug = std::getenv("SGPU_DEBUG") != nullptr;
-  double t_last = omp_get_wtime();
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_last = debug ? now() : 0.0;
   auto lap = [&](const char* what) {
-    const double t = omp_get_wtime();
-    if (debug) std::fprintf(stderr, "sgpu build: %-28s %.2f s\n", what, t - t_last);
+    if (!debug) return;
+    const double t = now();
+    std::fprintf(stderr, "sgpu build: %-28s %.2f s\n", what, t - t_last);
     t_last = t;
   };
   try {

@@ -36,7 +36,8 @@ sgpu_status sgpu_dataset_read(const char* path, uint64_t* n_vecs, uint64_t* nnz,
   static_assert(sizeof(float) == 4, "f32");
   uint32_t n = 0;
   if (fread(&n, 4, 1, in.f) != 1) return fail(SGPU_EIO, "%s: missing vector count", path);
-  const bool fill = offsets && (comps || vals);
+  if (offsets && (!comps || !vals)) return fail(SGPU_EINVAL, "offsets given without components / values buffers");
+  const bool fill = offsets != nullptr;
   const uint64_t cap_vecs = *n_vecs, cap_nnz = *nnz;
   if (fill && cap_vecs < n) return fail(SGPU_EINVAL, "%s holds %u vectors, room for %llu", path, n, (unsigned long long)cap_vecs);
   uint64_t total = 0;

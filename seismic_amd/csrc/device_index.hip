@@ -87,7 +87,7 @@ struct DeviceIndex {
   uint32_t value_type = SGPU_VAL_F16;   // how the records store document values
   float val_scale = 0.0f;
   bool fwd_block_major = false;   // forward store holds a copy of every posting's record, block by block
-  static constexpr int kMainEvents = 64, kPool = 6;
+  static constexpr int kMainEvents = 64, kPool = 8;   // two concurrent calls of four chunks each
   Lane main;
   Lane pool[kPool];
   std::unordered_map<uint64_t, int> occupancy;   // kernel variant + LDS size -> workgroups per CU

@@ -209,8 +209,10 @@ sgpu_status host_index_save(const HostIndex& ix, const char* path) {
   // the reference serialises InvertedIndexBase{.., knn} in one file too (src/inverted_index.rs:39-52)
   uint32_t scale_bits = 0;
   std::memcpy(&scale_bits, &ix.val_scale, 4);
+  // (a graph without a single neighbour - no document had one - is written as "no graph": the loader takes
+  // knn_dim == 0 and an empty neighbour array together)
   uint64_t hdr[kHdr] = {ix.comp_width,   ix.n_docs,   ix.dim,         ix.nnz(),   ix.n_blocks(),
-                        ix.n_postings(), ix.n_rows(), ix.n_entries(), ix.knn_dim, ix.knn.size(),
+                        ix.n_postings(), ix.n_rows(), ix.n_entries(), ix.knn.empty() ? 0u : ix.knn_dim, ix.knn.size(),
                         ix.value_type,   scale_bits};
   bool ok = fwrite(kMagic, 1, 8, f) == 8 && fwrite(hdr, 8, kHdr, f) == kHdr && wr(f, ix.fwd_offsets) &&
             wr(f, ix.fwd_comps) && wr(f, ix.fwd_vals) && wr(f, ix.fwd_codes) && wr(f, ix.list_block_start) &&
@@ -226,10 +228,26 @@ sgpu_status host_index_load(const char* path, HostIndex* out) {
   FILE* f = fopen(path, "rb");
   if (!f) return fail(SGPU_EIO, "cannot open %s: %s", path, strerror(errno));
   char magic[8];
-  uint64_t hdr[kHdr];
-  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kMagic, 8) != 0 || fread(hdr, 8, kHdr, f) != kHdr) {
+  uint64_t hdr[kHdr] = {0};
+  // SGPUIDX1 (round 1): 10-word header (no value type / scale words), f16 values - the same arrays otherwise
+  static const char kMagic1[8] = {'S', 'G', 'P', 'U', 'I', 'D', 'X', '1'};
+  bool got = fread(magic, 1, 8, f) == 8;
+  const bool v1 = got && memcmp(magic, kMagic1, 8) == 0;
+  got = got && (v1 || memcmp(magic, kMagic, 8) == 0);
+  if (got && v1) {
+    uint64_t h1[10];
+    got = fread(h1, 8, 10, f) == 10;
+    if (got) {   // the v2 header's first ten words; f16 values, no value scale
+      for (int i = 0; i < 10; ++i) hdr[i] = h1[i];
+      hdr[10] = SGPU_VAL_F16;
+      hdr[11] = 0;
+    }
+  } else if (got) {
+    got = fread(hdr, 8, kHdr, f) == kHdr;
+  }
+  if (!got) {
     fclose(f);
-    return fail(SGPU_EIO, "%s is not an SGPUIDX2 index file", path);
+    return fail(SGPU_EIO, "%s is not an SGPUIDX1 / SGPUIDX2 index file", path);
   }
   HostIndex& h = *out;
   h.comp_width = (uint32_t)hdr[0];

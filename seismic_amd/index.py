@@ -273,9 +273,21 @@ class _IndexBase:
         ix = _native.NativeIndex.build(cls._CW, max(len(tm), 1), off, c, v,
                                        _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy,
                                             max_fraction, doc_cut, num_threads))
-        self = cls(ix, tm, ids, contents if load_content else None, device, upload or bool(nknn))
+        return cls._finish_build(ix, nknn, device, upload, tm, ids, contents if load_content else None)
+
+    @classmethod
+    def _finish_build(cls, ix, nknn, device, upload, *meta):
+        """The kNN graph is built on the index AS BUILT (u16/f16), before a class converts its forward index: the
+        reference runs Index::from_file(..).knn(..) first and convert_dataset_into afterwards
+        (src/pylib/dotvbyte.rs:193-209), so SeismicIndexDotVByte's graph is SeismicIndex's graph."""
         if nknn:
-            self.build_knn(nknn)
+            ix.upload(device)      # Knn::new runs as batches through the GPU kernel
+            ix.build_knn(nknn)
+        self = cls(ix, *meta, device, False)
+        if self._ix is ix and nknn:
+            self._uploaded = True              # (not converted: the upload above is the index's)
+        elif upload or nknn:
+            self._ensure_device()
         return self
 
     @classmethod
@@ -288,10 +300,7 @@ class _IndexBase:
         ix = _native.NativeIndex.build(cls._CW, max(len(tm), 1), off, c, v,
                                        _cfg(n_postings, centroid_fraction, min_cluster_size, summary_energy,
                                             max_fraction, doc_cut, num_threads))
-        self = cls(ix, tm, list(dataset._ids), list(dataset._contents), device, upload or bool(nknn))
-        if nknn:
-            self.build_knn(nknn)
-        return self
+        return cls._finish_build(ix, nknn, device, upload, tm, list(dataset._ids), list(dataset._contents))
 
     @classmethod
     def load(cls, index_path, device=0, upload=True):

@@ -348,3 +348,30 @@ def test_exact_search_validates_its_queries():
         with pytest.raises(_native.SeismicHipError) as e:
             ix.exact_search(np.array(q_off, np.uint64), np.array(c, np.uint32), np.array(v, np.float32), 5)
         assert e.value.status == 1
+
+
+def test_round_1_index_files_still_load(tmp_path):
+    """SGPUIDX1 files (10-word header, f16 values) written by round 1 load as what they hold; a dataset
+    read with offsets but without value buffers is refused instead of written through a null pointer."""
+    off, comps, vals = random_dataset(3, 400, 300, nnz_lo=2, nnz_hi=30)
+    ix = _native.NativeIndex.build(2, 300, off, comps, vals, BuildConfig.defaults(n_postings=50, centroid_fraction=0.2))
+    p2, p1 = str(tmp_path / "v2.idx"), str(tmp_path / "v1.idx")
+    ix.save(p2)
+    raw = open(p2, "rb").read()
+    assert raw[:8] == b"SGPUIDX2"
+    open(p1, "wb").write(b"SGPUIDX1" + raw[8:8 + 80] + raw[8 + 96:])      # drop the two words round 2 added
+    old = _native.NativeIndex.load(p1)
+    from util import desc_equal
+    desc_equal(old.desc, ix.desc)
+    assert old.desc.value_type == 0
+    open(p1, "wb").write(b"SGPUIDX0" + raw[8:])
+    with pytest.raises(_native.SeismicHipError):
+        _native.NativeIndex.load(p1)
+    dp = str(tmp_path / "d.bin")
+    _native.write_inner_format(dp, off, comps, vals)
+    n, nnz = ctypes.c_uint64(len(off) - 1), ctypes.c_uint64(len(comps))
+    o = np.zeros(len(off), np.uint64)
+    c = np.zeros(len(comps), np.uint32)
+    st = _native.lib().sgpu_dataset_read(os.fsencode(dp), ctypes.byref(n), ctypes.byref(nnz), o.ctypes.data_as(ctypes.c_void_p),
+                                         c.ctypes.data_as(ctypes.c_void_p), None)
+    assert st == 1      # SGPU_EINVAL

@@ -81,7 +81,8 @@ def test_bench_on_files_in_the_reference_formats(tmp_path):
     _native.write_results_tsv(gp, es, ei, en)
     env = dict(os.environ, SGPU_INDEX_CACHE=str(tmp_path))
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--documents", dp, "--queries-file", qp, "--groundtruth", gp,
-           "--results-tsv", rp, "--n-postings", "300", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-latency", "--no-e2e"]
+           "--results-tsv", rp, "--n-postings", "300", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-latency", "--no-e2e",
+           "--target-recall", "0.5,0.999999"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
@@ -91,6 +92,11 @@ def test_bench_on_files_in_the_reference_formats(tmp_path):
     hit = sum(len(set(res[i]) & set(gt[i])) for i in range(300)) / 3000.0
     assert out["accuracy_vs_groundtruth"] == pytest.approx(hit) and hit > 0.8
     assert out["recall_at_k"] == pytest.approx(hit)        # the same quantity, computed by bench against exact search
+    assert out["entry_point"]["rows_identical_to_device_resident_launch"] is True
+    op = out["operating_points"]                            # fixed-recall operating points, each checked against the oracle
+    assert op[0]["reached"] and op[0]["recall_at_k"] >= 0.5 and op[0]["identical_to_cpu_oracle_on_sample"] is True
+    assert op[0]["value"] > 0 and 0 < op[0]["roofline_frac"] < 1
+    assert op[1]["target_recall"] == 0.999999 and (op[1]["reached"] or op[1]["best_recall_on_grid"] < 0.999999)
     ix.upload(0)                                            # the TSV holds exactly what the API returns
     gs, gi, gn = ix.batch_search(*q, 10, 4, 1.0, False)
     assert [int(x) for x in gi[7, :gn[7]]] == res[7]

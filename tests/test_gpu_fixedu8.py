@@ -99,3 +99,21 @@ def test_dotvbyte_class_through_the_python_api():
     for r, e in zip(res, exp):
         assert [d for _, _, d in r][:3] == [d for _, _, d in e][:3]                   # same leaders
         assert all(abs(a[1] - b[1]) < 0.2 for a, b in zip(r, e))                      # scores within the 8-bit step
+
+
+def test_dotvbyte_graph_is_the_graph_of_the_index_as_built():
+    """SeismicIndexDotVByte.build(nknn=...) builds the kNN graph on the u16/f16 index and converts the
+    forward index afterwards (reference src/pylib/dotvbyte.rs:193-209: Index::from_file(..).knn(..), then
+    convert_dataset_into): its graph is SeismicIndex's graph, not one computed on 8-bit values."""
+    path = os.path.join(GOLD, "toy", "documents.jsonl")
+    ix = seismic_amd.SeismicIndexDotVByte.build(path, nknn=3)
+    ref = seismic_amd.SeismicIndex.build(path, nknn=3)
+    a, da = ix._ix.get_knn()
+    b, db = ref._ix.get_knn()
+    assert ix._ix.desc.value_type == 1 and da == db == 3 and len(a) == len(b) > 0
+    assert np.array_equal(a, b)
+    qids, vecs, _ = seismic_amd.index.read_jsonl(os.path.join(GOLD, "toy", "queries.jsonl"))
+    comps = [np.array(list(v.keys()), dtype=seismic_amd.get_seismic_string()) for v in vecs]
+    vals = [np.array(list(v.values()), dtype=np.float32) for v in vecs]
+    res = ix.batch_search(np.array(qids, dtype="U30"), comps, vals, k=5, query_cut=3, heap_factor=0.9, n_knn=2)
+    assert len(res) == len(qids) and all(len(r) > 0 for r in res)
