@@ -8,7 +8,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/$1"; shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu --no-recall --no-latency --no-e2e $*"
+BENCH="python $REPO/bench.py --no-entry --no-cpu --no-recall --no-latency --no-e2e $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH --steps 20 --warmup 3 > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 for C in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS" "TCC_HIT_sum TCC_MISS_sum" "SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $C | tr ' ' '_' | cut -c1-40)

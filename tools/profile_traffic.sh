@@ -7,7 +7,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT="$REPO/$1"; shift
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu --no-recall --no-latency --no-e2e $*"
+BENCH="python $REPO/bench.py --no-entry --no-cpu --no-recall --no-latency --no-e2e $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace_bench.json" 2> "$OUT/trace.err"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- $BENCH --no-accounting --steps 4 --warmup 1 > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
@@ -28,6 +28,9 @@ def counter(tag, name):
     return best
 f, w = counter("pmc_FETCH_SIZE", "FETCH_SIZE"), counter("pmc_WRITE_SIZE", "WRITE_SIZE")
 ent = {"traffic_bytes": int(2 * f["mean"] * 1024 + w["mean"] * 1024), "fetch_size_kib": int(f["mean"]),
-       "write_size_kib": int(w["mean"]), "dispatches": f["dispatches"]}
+       "write_size_kib": int(w["mean"]), "dispatches": f["dispatches"],
+       "kernel_source_id": line["roofline"]["kernel_source_id"],   # bench.py reports the figure only for this kernel source
+       "algorithmic_bytes": json.loads(open(out + "/trace_bench.json").read().strip().splitlines()[-1])["roofline"]["algorithmic_bytes_per_launch"]}
+ent["ratio"] = round(ent["traffic_bytes"] / ent["algorithmic_bytes"], 4) if ent["algorithmic_bytes"] else None
 print(json.dumps({line["config"]["workload_key"]: ent}, indent=1))
 PY
