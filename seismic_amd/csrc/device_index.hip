@@ -24,10 +24,16 @@ hipError_t run_u32_packed(const LaunchArgs& a, int* occupancy);
 hipError_t run_u32_hash(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_dense_u8(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_packed_u8(const LaunchArgs& a, int* occupancy);
+hipError_t run_u32_packed_u8(const LaunchArgs& a, int* occupancy);
+hipError_t run_u16_hash(const LaunchArgs& a, int* occupancy);
+hipError_t run_u16_hash_u8(const LaunchArgs& a, int* occupancy);
+hipError_t run_u32_split_u8(const LaunchArgs& a, int* occupancy);
 
 static hipError_t run_any(const LaunchArgs& a, int* occ) {
-  if (a.value_type == SGPU_VAL_FIXEDU8) return a.lookup == LK_DENSE ? run_u16_dense_u8(a, occ) : run_u16_packed_u8(a, occ);
-  if (a.comp_width == 2) return a.lookup == LK_DENSE ? run_u16_dense(a, occ) : run_u16_packed(a, occ);
+  if (a.value_type == SGPU_VAL_FIXEDU8 && a.comp_width == 4) return a.lookup == LK_SPLIT ? run_u32_split_u8(a, occ) : run_u32_packed_u8(a, occ);
+  if (a.value_type == SGPU_VAL_FIXEDU8)
+    return a.lookup == LK_HASH ? run_u16_hash_u8(a, occ) : (a.lookup == LK_DENSE ? run_u16_dense_u8(a, occ) : run_u16_packed_u8(a, occ));
+  if (a.comp_width == 2) return a.lookup == LK_HASH ? run_u16_hash(a, occ) : (a.lookup == LK_DENSE ? run_u16_dense(a, occ) : run_u16_packed(a, occ));
   if (a.lookup == LK_HASH) return run_u32_hash(a, occ);
   return a.lookup == LK_SPLIT ? run_u32_split(a, occ) : run_u32_packed(a, occ);
 }
@@ -674,16 +680,16 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
                      [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) { return a.first > c.first; });
     pl.order.resize(2 * (size_t)nq);
     for (uint32_t i = 0; i < nq; ++i) pl.order[i] = cost[i].second;
-    // LK_HASH seeds (large vocabularies): the first multiplier of the family that sends the query's
-    // components to distinct slots; queries of more than 255 components cannot use the byte table
-    pl.hash_ok = d->comp_width == 4;
+    // LK_HASH seeds: the first multiplier of the family that sends the query's components to distinct slots
+    // (component ids below 2^24; a query may fill at most a quarter of the table)
+    pl.hash_ok = d->view.dim < (1u << 24) && !env_u32("SGPU_NO_HASH", 0);
     if (pl.hash_ok) {
       std::vector<uint32_t> stamp(kHashSlots, 0xffffffffu);
       uint32_t epoch = 0;
       for (uint32_t q = 0; q < nq && pl.hash_ok; ++q) {
         const uint64_t a = h_off[q], e = h_off[q + 1];
         uint32_t seed = kHashSeeds;
-        if (e - a <= 255)
+        if (e - a <= kHashSlots / 4)
           for (uint32_t s = 0; s < kHashSeeds && seed == kHashSeeds; ++s) {
             const uint32_t mult = hash_mult(s);
             bool clash = false;
@@ -813,6 +819,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   // the round's item tables shrink (down to 256 items) if that is what keeps 2 workgroups per CU
   auto uni_for = [&](uint32_t items) { return up(std::max<uint64_t>((uint64_t)items * 16 + NT * 12, sort_bytes)); };
   const uint64_t smallest_lookup = (d->comp_width == 4) ? split_bytes : bitmap_bytes;
+  const uint32_t want_items = items_max;
   if (!std::getenv("SGPU_ITEMS_MAX")) {
     const uint32_t want = items_max;
     if (dense_ok)   // the dense table is worth smaller rounds (down to 512 items)
@@ -829,22 +836,36 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   const bool split = !dense && d->comp_width == 4 && b->max_nnz <= 65535 &&
                      (o + bitmap_bytes + min_uni > budget || env_u32("SGPU_FORCE_SPLIT", 0)) &&
                      !env_u32("SGPU_NO_SPLIT", 0);
-  // large vocabularies, u32 components: a 32 KB hashed byte table (one random LDS read per document
-  // component, then a verified entry) when every query of the batch has a collision-free seed, the
-  // launch order (which carries the seeds) is in use, and it fits at 2 workgroups per CU
-  const uint64_t hash_bytes = (uint64_t)kHashSlots + up(((uint64_t)qn + 1) * 8);
-  const bool hashed = !dense && searching && d->comp_width == 4 && pl && pl->hash_ok && b->max_nnz <= 255 &&
-                      !env_u32("SGPU_NO_LPT", 0) && !env_u32("SGPU_NO_HASH", 0) && d->value_type == SGPU_VAL_F16 &&
-                      (o + hash_bytes + min_uni <= budget || env_u32("SGPU_FORCE_HASH", 0)) &&
-                      !env_u32("SGPU_FORCE_SPLIT", 0);
-  const uint32_t lookup = dense ? LK_DENSE : (hashed ? LK_HASH : (split ? LK_SPLIT : LK_PACKED));
+  // hashed {component id, weight} entries (32 KB): ONE LDS read per document component where the dense byte
+  // table needs two (profiles/r03_lds_sensitivity.md) - preferred whenever every query of the batch has a
+  // collision-free seed, the launch order (which carries the seeds) is in use, and it fits at 2 workgroups
+  // per CU (the round's item tables shrink for it as they do for the dense table)
+  const uint64_t hash_bytes = (uint64_t)kHashSlots * 8;
+  const bool hash_family = !(d->comp_width == 4 && d->value_type == SGPU_VAL_FIXEDU8);   // (no u32 + fixed-u8 hashed kernels)
+  // (measured r03 on the 8.8M-document shape, u16 components: 6.46 ms per launch against the dense byte
+  // table's 5.81 - a random 8-byte read costs two bank passes where the byte read costs one and the dense
+  // layout's second read is mostly a broadcast of one address; fixed-u8 6.36 against 5.56. The hashed
+  // entries therefore serve u32 components, where they replace a byte read PLUS an 8-byte read; for u16
+  // they are used when the dense table is not available or on request, SGPU_FORCE_HASH=1.)
+  bool hashed = searching && hash_family && pl && pl->hash_ok && !env_u32("SGPU_NO_LPT", 0) && !env_u32("SGPU_NO_HASH", 0) &&
+                !env_u32("SGPU_FORCE_SPLIT", 0) && !env_u32("SGPU_FORCE_DENSE", 0) &&
+                (d->comp_width == 4 || !dense || env_u32("SGPU_FORCE_HASH", 0));
+  if (hashed && !std::getenv("SGPU_ITEMS_MAX") && !env_u32("SGPU_FORCE_HASH", 0)) {
+    uint32_t im = want_items;
+    while (im > 512 && o + hash_bytes + uni_for(im) > budget) im -= 128;
+    if (o + hash_bytes + uni_for(im) <= budget) items_max = im;
+    else hashed = false;
+  } else if (hashed && !env_u32("SGPU_FORCE_HASH", 0) && o + hash_bytes + uni_for(items_max) > budget) {
+    hashed = false;
+  }
+  const uint32_t lookup = hashed ? LK_HASH : (dense ? LK_DENSE : (split ? LK_SPLIT : LK_PACKED));
   const uint64_t lookup_bytes =
-      mode == MODE_DOTS ? 0u : (dense ? dense_bytes : (hashed ? hash_bytes : (split ? split_bytes : bitmap_bytes)));
+      mode == MODE_DOTS ? 0u : (hashed ? hash_bytes : (dense ? dense_bytes : (split ? split_bytes : bitmap_bytes)));
   L.q_bits = (uint32_t)o;
-  L.q_rank = (uint32_t)(o + (hashed ? (uint64_t)kHashSlots : (split ? split_bits : lookup_bytes)));
+  L.q_rank = (uint32_t)(o + (split && !hashed ? split_bits : lookup_bytes));
   o += lookup_bytes;
   L.uni = (uint32_t)std::min<uint64_t>(o, 0xffffffffu);
-  const uint64_t uni = min_uni;
+  const uint64_t uni = uni_for(items_max);
   o += uni;
   L.qc = qc;
   L.qn = qn;

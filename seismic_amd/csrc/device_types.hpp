@@ -47,25 +47,26 @@ struct BatchView {
 };
 
 enum { MODE_SEARCH = 0, MODE_DOTS = 1, MODE_COUNTED = 2 };   // COUNTED: search with the visited bitmap (exact counters)
-// query lookup table in LDS: {32 bits, rank} per 32 ids | one byte per id | bits + 16-bit ranks
+// query lookup table in LDS: {32 bits, rank} per 32 ids | one byte per id | bits + 16-bit ranks | hashed {id, weight} entries
 enum { LK_PACKED = 0, LK_DENSE = 1, LK_SPLIT = 2, LK_HASH = 3 };
-// LK_HASH (large vocabularies): one byte per slot of a 32768-slot table addressed by a hash of the
-// component id, holding 1 + rank of the query component in that slot (0 = empty), verified against the
-// component stored with the weight. The host picks, per query, a multiplier of this family under which
-// the query's components do not collide (make_plan); a batch with a query for which none works uses
-// another layout.
-enum { kHashSlots = 32768, kHashSeeds = 16 };
+// LK_HASH: a table of kHashSlots 8-byte entries {component id, weight bits} addressed by a multiplicative
+// hash of the component id; an empty slot holds the id 0xffffffff. A document component costs ONE LDS read
+// (ds_read_b64) and a compare. Used for u32 components (large vocabularies) and, for u16 components, where
+// the dense byte table is not available (measurements: profiles/r03_lds_sensitivity.md). The host picks, per query, a multiplier of this family under which the
+// query's components fall into distinct slots (make_plan); a batch with a query for which none of the
+// kHashSeeds works uses another layout. Component ids below 2^24 (v_mul_u32_u24).
+enum { kHashBits = 12, kHashSlots = 1 << kHashBits, kHashSeeds = 64 };
 #if defined(__HIPCC__)
 #define SGPU_HD __host__ __device__
 #else
 #define SGPU_HD
 #endif
-SGPU_HD inline uint32_t hash_mult(uint32_t seed) {
-  constexpr uint32_t m[kHashSeeds] = {0x0001, 0x06a5, 0x1b87, 0x2f63, 0x3a95, 0x4c1f, 0x5d2b, 0x6e9d,
-                                      0x7b31, 0x0d4f, 0x19e3, 0x25c9, 0x31af, 0x43d7, 0x57a1, 0x69bb};
-  return m[seed & (kHashSeeds - 1)];
+SGPU_HD inline uint32_t hash_mult(uint32_t seed) {   // odd 24-bit multipliers
+  return (((seed + 1u) * 2654435761u) >> 8 | 1u) & 0xffffffu;
 }
-SGPU_HD inline uint32_t hash_slot(uint32_t c, uint32_t mult) { return (c ^ ((c >> 15) * mult)) & (kHashSlots - 1); }
+SGPU_HD inline uint32_t hash_slot(uint32_t c, uint32_t mult) {   // top bits of the low 32 bits of the 24 x 24-bit product
+  return (uint32_t)(((uint64_t)(c & 0xffffffu) * mult) & 0xffffffffull) >> (32 - kHashBits);
+}
 enum { STATS_WORDS = 24 };
 enum { kStateWords = 160 };   // per-workgroup state words in LDS (ST_* in search_kernel.hip)   // per-query stats: 8 work counters + 12 phase clocks (>>4) + slot + pad
 

@@ -69,7 +69,6 @@ sgpu_status validate_desc(const sgpu_index_desc& d) {
   if (d.value_type == SGPU_VAL_FIXEDU8) {
     int e = 0;
     if (!(d.val_scale > 0.0f) || std::frexp(d.val_scale, &e) != 0.5f) return fail(SGPU_EINVAL, "val_scale must be a positive power of two");
-    if (d.comp_width != 2) return fail(SGPU_EINVAL, "fixed-u8 values need u16 components (as the reference's DotVByte index does)");
   }
   if (d.comp_width == 2 && d.dim > 65536) return fail(SGPU_EINVAL, "dim %llu does not fit u16 components", (unsigned long long)d.dim);
   if (d.dim > 0xffffffffull || d.n_docs > 0x7fffffffull) return fail(SGPU_EINVAL, "dim/n_docs out of range");
@@ -308,8 +307,8 @@ sgpu_status host_index_load(const char* path, HostIndex* out) {
 // InvertedIndexBase::convert_dataset_into: same lists / blocks / summaries, the forward index re-encoded.
 sgpu_status host_index_convert(const HostIndex& src, uint32_t value_type, HostIndex* out) {
   if (value_type != SGPU_VAL_F16 && value_type != SGPU_VAL_FIXEDU8) return fail(SGPU_EINVAL, "unknown value_type %u", value_type);
-  if (value_type == SGPU_VAL_FIXEDU8 && src.comp_width != 2)
-    return fail(SGPU_EINVAL, "fixed-u8 values need u16 components (SeismicIndexDotVByte supports u16 only, src/pylib/dotvbyte.rs:20-27)");
+  // (either component width: the reference's "fixedu8" value type goes with u16 and with u32 components,
+  // src/bin/perf_inverted_index.rs:110-126; only its DotVByte class is u16-only, src/pylib/dotvbyte.rs:20-27)
   try {
     *out = src;
     HostIndex& h = *out;

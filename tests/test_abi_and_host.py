@@ -332,8 +332,8 @@ def test_convert_to_fixed_u8_host_side(tmp_path):
     assert np.array_equal(np.array(gv, np.float32), deq[off[5]:off[6]])
     back = u8.convert(0)                                                  # and back to f16: values are the dequantised codes
     assert back.desc.value_type == 0
-    with pytest.raises(_native.SeismicHipError):
-        _native.NativeIndex.build(4, 70000, *random_dataset(93, 50, 70000)).convert(1)   # u16 components only
+    lv = _native.NativeIndex.build(4, 70000, *random_dataset(93, 50, 70000)).convert(1)   # u32 components as well
+    assert lv.desc.value_type == 1 and lv.desc.comp_width == 4                            # ("fixedu8" + u32: perf_inverted_index.rs:125-126)
 
 
 def test_exact_search_validates_its_queries():

@@ -117,3 +117,28 @@ def test_dotvbyte_graph_is_the_graph_of_the_index_as_built():
     vals = [np.array(list(v.values()), dtype=np.float32) for v in vecs]
     res = ix.batch_search(np.array(qids, dtype="U30"), comps, vals, k=5, query_cut=3, heap_factor=0.9, n_knn=2)
     assert len(res) == len(qids) and all(len(r) > 0 for r in res)
+
+
+def test_fixed_u8_values_with_u32_components():
+    """The reference's "fixedu8" value type also goes with u32 components (src/bin/perf_inverted_index.rs:125-126):
+    large vocabulary, both lookup layouts the u32 kernels have for it, bit-identical to the oracle's restatement."""
+    from util import random_dataset, random_queries
+    dim = 90000
+    off, comps, vals = random_dataset(31, 4000, dim, nnz_lo=1, nnz_hi=300, empty_every=53)
+    cfg = BuildConfig.defaults(n_postings=300, centroid_fraction=0.2, summary_energy=0.5, max_fraction=6.0)
+    ix = _native.NativeIndex.build(4, dim, off, comps, vals, cfg).convert(1)
+    assert ix.desc.value_type == 1 and ix.desc.comp_width == 4
+    ix.upload(0)
+    o = orc.OracleIndex(4, dim, off, comps, vals, cfg).convert_fixedu8()
+    from util import desc_equal
+    desc_equal(ix.desc, o.desc)
+    q = random_queries(9, 80, dim, 3, 60)
+    for env in ({}, {"SGPU_FORCE_SPLIT": "1"}):
+        for k_, v_ in env.items():
+            os.environ[k_] = v_
+        try:
+            for k, cut, hf, srt in ((10, 4, 1.0, False), (100, 10, 0.8, True)):
+                _same(ix.batch_search(*q, k, cut, hf, srt), orc.batch_search(o.desc, *q, k, cut, hf, srt)[:3])
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)

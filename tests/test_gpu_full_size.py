@@ -64,6 +64,26 @@ def test_c5_large_vocabulary_1m_docs_k100_heap_factor_sweep():
     _same(g, orc.batch_search(ix.desc, *q, 100, 10, 0.9, True)[:3])
 
 
+def test_c5_large_vocabulary_full_size_5m_docs_k100_heap_factor_sweep():
+    """BASELINE config 5 at its FULL size: 5M docs x 200K vocabulary (u32 components), k=100, query_cut=10,
+    heap_factor in {0.7, 0.9, 1.0}: bit-identical to the oracle (its tuned path, itself asserted identical to
+    the restatement in tests/test_oracle_kat.py), in batch and through single-query cooperative launches."""
+    dim, n_docs, nq = 200_000, 5_000_000, 200
+    docs = _native.synth(n_docs, dim, 42, 0)
+    ix = _native.NativeIndex.build(4, dim, *docs, BuildConfig.defaults(n_postings=2000, centroid_fraction=0.1,
+                                                                        summary_energy=0.4, max_fraction=4.0,
+                                                                        min_cluster_size=10, use_device=1))
+    ix.upload(0)
+    q = _native.synth(nq, dim, 43, 1, docs)
+    del docs
+    for hf in (0.7, 0.9, 1.0):
+        c = orc.batch_search(ix.desc, *q, 100, 10, hf, False, tuned=True)[:3]
+        _same(ix.batch_search(*q, 100, 10, hf, False), c)
+        if hf == 0.9:
+            _same(ix.search_sequential(q[0][:41], q[1], q[2], 100, 10, hf, False)[:3], tuple(a[:40] for a in c))
+            assert (c[2] == 100).all()
+
+
 def test_accumulation_order_tolerance_at_full_size(capsys):
     """The document-score accumulation order lives in vectorium (not in the reference tree); the
     kernel's order (16 lane accumulators + butterfly) is bit-exact against the oracle's LANES16

@@ -63,8 +63,8 @@ def test_differential(seed, monkeypatch):
     if seed >= 14 and seed % 3 == 0:
         cfg["use_device"] = 1
     ix = _native.NativeIndex.build(cw, dim, off, comps, vals, BuildConfig.defaults(**cfg))
-    if seed >= 14 and cw == 2 and seed % 2 == 0:
-        ix = ix.convert(1)                      # fixed-u8 document values (negative weights quantise to 0)
+    if seed >= 14 and seed % 2 == 0:
+        ix = ix.convert(1)                      # fixed-u8 document values (negative weights quantise to 0); u16 and u32 components
     if seed >= 14 and seed % 5 == 0:
         ix.upload_many([0, 0])                  # two replicas: batches are sharded over them
     else:
