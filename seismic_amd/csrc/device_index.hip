@@ -481,6 +481,8 @@ struct sgpu_batch {
   bool staged = false;
   uint8_t* arena_dev = nullptr;
   uint8_t* arena_host = nullptr;
+  uint8_t* arena_host_dev = nullptr;   // the pinned host arena as the device sees it (small calls write their rows straight into it)
+  bool direct_out = false;
   size_t arena_cap = 0, in_bytes = 0, out_off = 0, out_bytes = 0;
   uint32_t* queue_dev = nullptr;
 };
@@ -1208,10 +1210,11 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     b->owner = d;
     b->arena_cap = std::max<size_t>(total + total / 4, 1 << 16);   // some room: a stream of similar calls settles
     if (hipMalloc((void**)&b->arena_dev, b->arena_cap) != hipSuccess ||
-        hipHostMalloc((void**)&b->arena_host, b->arena_cap, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void**)&b->arena_host, b->arena_cap, hipHostMallocMapped) != hipSuccess) {
       batch_free(b);
       return fail(SGPU_ENOMEM, "allocation of a %zu-byte staging arena failed", b->arena_cap);
     }
+    if (hipHostGetDevicePointer((void**)&b->arena_host_dev, b->arena_host, 0) != hipSuccess) b->arena_host_dev = nullptr;
     *slot = b;
     if (std::getenv("SGPU_DEBUG_ALLOC")) std::fprintf(stderr, "sgpu alloc: arena %p..%p\n", (void*)b->arena_dev, (void*)(b->arena_dev + b->arena_cap));
   }
@@ -1248,9 +1251,15 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   b->q_val = (float*)(b->arena_dev + o_val);
   b->q_order = (uint32_t*)(b->arena_dev + o_order);
   b->order_cut = cut;
-  b->out_n = (uint32_t*)(b->arena_dev + r_n);
-  b->out_scores = (float*)(b->arena_dev + r_sc);
-  b->out_ids = (uint64_t*)(b->arena_dev + r_id);
+  // A latency-bound call (a handful of queries) has the kernel write its few result rows straight into the pinned
+  // host arena (mapped, fine-grained: posted writes over PCIe, visible once the stream is done): no D2H copy to
+  // enqueue, none to wait for. Larger calls keep the device-side slab and one D2H.
+  static const uint32_t direct_max = env_u32("SGPU_DIRECT_OUT_MAX", 16);
+  b->direct_out = b->arena_host_dev != nullptr && nq <= direct_max;
+  uint8_t* out_base = b->direct_out ? b->arena_host_dev : b->arena_dev;
+  b->out_n = (uint32_t*)(out_base + r_n);
+  b->out_scores = (float*)(out_base + r_sc);
+  b->out_ids = (uint64_t*)(out_base + r_id);
   b->out_stats = nullptr;
   pc.lap(1);
   HIP_TRY(hipMemcpyAsync(b->arena_dev, hs, in_bytes, hipMemcpyHostToDevice, lane->stream));
@@ -1264,7 +1273,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     if (st == SGPU_OK) he = launch_search(a);
   }
   pc.lap(3);
-  if (st == SGPU_OK && he == hipSuccess)
+  if (st == SGPU_OK && he == hipSuccess && !b->direct_out)
     he = hipMemcpyAsync(hs + r_n, b->arena_dev + r_n, b->out_bytes, hipMemcpyDeviceToHost, lane->stream);
   pc.lap(4);
   if (st != SGPU_OK || he != hipSuccess) {
