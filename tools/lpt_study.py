@@ -29,7 +29,8 @@ slots = len(set(st[:, 20].astype(int)))
 a = orc.desc_arrays(ix.desc)
 lb, bp = a["list_block_start"].astype(np.int64), a["block_post_start"].astype(np.int64)
 lrs, rp = a["list_row_start"].astype(np.int64), a["row_ptr"].astype(np.int64)
-feat = {"postings": [], "blocks": [], "nnz": [], "entries_of_lists": []}
+feat = {"postings": [], "blocks": [], "nnz": [], "entries_of_lists": [], "postings x w/w1": [], "postings x (w/w1)^2": [],
+        "postings of list 1": [], "postings / sum(w top4)": [], "postings x w/sum(w)": [], "sum(w) all": [], "w1": []}
 for i in range(nq):
     c, v = qc[q_off[i]:q_off[i + 1]], qv[q_off[i]:q_off[i + 1]]
     top = c[np.argsort(-v, kind="stable")[:4]]
@@ -37,6 +38,15 @@ for i in range(nq):
     feat["blocks"].append(sum(lb[x + 1] - lb[x] for x in top))
     feat["nnz"].append(len(c))
     feat["entries_of_lists"].append(sum(rp[lrs[x + 1]] - rp[lrs[x]] for x in top))
+    wt = np.sort(v)[::-1][:4].astype(np.float64)
+    npl = np.array([bp[lb[x + 1]] - bp[lb[x]] for x in top], np.float64)
+    feat["postings x w/w1"].append(float((npl * wt / wt[0]).sum()))
+    feat["postings x (w/w1)^2"].append(float((npl * (wt / wt[0]) ** 2).sum()))
+    feat["postings of list 1"].append(float(npl[0]))
+    feat["postings / sum(w top4)"].append(float(npl.sum() / wt.sum()))
+    feat["postings x w/sum(w)"].append(float((npl * wt).sum() / float(v.sum())))
+    feat["sum(w) all"].append(float(v.sum()))
+    feat["w1"].append(float(wt[0]))
 F = {k: np.array(v, np.float64) for k, v in feat.items()}
 F["docs_scored (a posteriori)"] = st[:, 7]
 F["postings + 40 nnz"] = F["postings"] + 40 * F["nnz"]
