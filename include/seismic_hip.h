@@ -76,7 +76,9 @@ typedef enum sgpu_status {
  *                    quantization (Q0.8)", docs/TomlInstructions.md:100). The codec is not in the
  *                    reference tree: PARITY UNPINNED. Restated as: val_scale = the smallest power of
  *                    two with 255 * val_scale >= the largest value (2^-8, i.e. Q0.8, for values
- *                    below 1); code = min(255, round_half_away(v / val_scale)), negatives -> 0. */
+ *                    below 1); code = min(255, round_half_away(v / val_scale)), negatives -> 0.
+ *                    Either component width (the reference's "fixedu8" goes with u16 and u32 components,
+ *                    src/bin/perf_inverted_index.rs:110-126; its DotVByte class is u16-only). */
 enum { SGPU_VAL_F16 = 0, SGPU_VAL_FIXEDU8 = 1 };
 
 typedef struct sgpu_index_desc {
