@@ -969,11 +969,11 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
                                              uni_bytes / 16);
       c.chunk_min = std::min<uint32_t>(c.chunk, std::max<uint32_t>(env_u32("SGPU_COOP_CHUNK_MIN", 4), 1u));
       c.min_items = env_u32("SGPU_COOP_MIN_ITEMS", 64);
-      c.first_reach = std::max<uint32_t>(1, env_u32("SGPU_COOP_FIRST_REACH", 384));
+      c.first_reach = std::max<uint32_t>(1, env_u32("SGPU_COOP_FIRST_REACH", 256));
       c.idle_min = env_u32("SGPU_COOP_IDLE_MIN", force ? 0 : 8);
       c.idle_ratio = env_u32("SGPU_COOP_IDLE_RATIO", force ? 0 : 8);
       c.poll_sleep = std::max<uint32_t>(1, env_u32("SGPU_COOP_POLL", 2));
-      c.enabled = 1u | (env_u32("SGPU_COOP_DEBUG", 0) << 8);
+      c.enabled = 1u;
       const size_t o_slots = 128, o_pos = o_slots + (size_t)grid * kCoopSlotWords * 8,
                    o_cand = o_pos + (size_t)grid * c.max_pos * 8, o_trace = o_cand + (size_t)grid * c.max_cand * 16,
                    total = o_trace + (size_t)grid * 16 * 8;
@@ -1011,7 +1011,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   }
   // latency-bound launches bootstrap the threshold with ONE local round before they go wide
   if (a->coop.enabled && b->nq <= d->n_cu && !std::getenv("SGPU_ITEMS_INIT"))
-    a->p.items_init = std::min<uint32_t>(a->p.items_max, std::max<uint32_t>(1, env_u32("SGPU_COOP_ITEMS_INIT", 64)));
+    a->p.items_init = std::min<uint32_t>(a->p.items_max, std::max<uint32_t>(1, env_u32("SGPU_COOP_ITEMS_INIT", 128)));
   if (!a->coop.enabled) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
   a->grid = grid;
   // visited bitmaps: one per resident workgroup (counted pass)
