@@ -663,8 +663,11 @@ def main():
         ncores = os.cpu_count() or 1
         q = (s_off, s_comp, s_val)
         kw = dict(tuned=True)
-        orc.batch_search(d, *q, args.k, args.query_cut, args.heap_factor, srt, num_threads=1, **kw)
-        osc, oid, on, ost, secs1, _ = orc.batch_search(d, *q, args.k, args.query_cut, args.heap_factor, srt, num_threads=1, **kw)
+        singles = []
+        for _ in range(3):   # single thread: three passes over the sample, the fastest one is reported
+            osc, oid, on, ost, secs1, _ = orc.batch_search(d, *q, args.k, args.query_cut, args.heap_factor, srt, num_threads=1, **kw)
+            singles.append(secs1)
+        secs1 = min(singles)
         identical = bool(np.array_equal(on, gn[:ns]) and np.array_equal(oid, gid[:ns])
                          and np.array_equal(osc.view(np.uint32), gsc[:ns].view(np.uint32)))
         qps1 = ns / secs1
@@ -691,8 +694,9 @@ def main():
         out["cpu_baseline"] = {
             "value": qpsn, "unit": "queries/s", "cores": int(used), "kind": "port",
             "sample": "the first %d queries of the first timed batch: %d passes on %d pinned OpenMP threads (one query "
-                      "per task) after a thread-count sweep; single thread: second of 2 passes" % (ns, runs_n, used),
+                      "per task) after a thread-count sweep; single thread: fastest of 3 passes" % (ns, runs_n, used),
             "single_thread_qps": qps1, "single_thread_us_per_query": 1e6 / qps1,
+            "single_thread_passes_us_per_query": [x * 1e6 / ns for x in singles],
             "host_cores": ncores, "thread_sweep_qps": {str(k_): v_ for k_, v_ in sorted(sweep.items())},
             "gpu_results_identical_to_cpu": identical,
             "implementation": "oracle/seismic_oracle.cpp search_one<true>: AVX2+F16C scorer, hash-set visited set, range prefetch",
