@@ -297,9 +297,14 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
     Lane* lane;
     uint32_t q0, q1;
   };
-  Job jobs[4];
+  static const uint32_t chunk_max = [] {   // (experiments: SGPU_CHUNK_MAX; the default of four was the fastest measured)
+    const char* v = std::getenv("SGPU_CHUNK_MAX");
+    const uint32_t n = v && *v ? (uint32_t)std::strtoul(v, nullptr, 10) : 4u;
+    return n < 1 ? 1u : (n > 8 ? 8u : n);
+  }();
+  Job jobs[8];
   uint32_t n_jobs = 1;
-  if (chunk_min && nq >= 2 * chunk_min) n_jobs = std::min<uint32_t>(4, nq / chunk_min);
+  if (chunk_min && nq >= 2 * chunk_min) n_jobs = std::min<uint32_t>(chunk_max, nq / chunk_min);
   std::vector<uint64_t> off;   // a chunk's offsets, rebased (sized here: nothing below allocates host memory)
   if (n_jobs > 1) {
     try {
