@@ -1,10 +1,18 @@
+"""Kernel time of mid-size launches (256 ... 2500 queries) on the 8.8M-document shape; SGPU_COOP* knobs are honoured."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, '/root/repo')
 from seismic_amd import _native
 n=8800000
 docs = _native.synth(n, 30000, 42, 0)
-ix = _native.NativeIndex.load("/tmp/lat_%d.idx" % n)
+path = "/tmp/lat_%d.idx" % n
+if os.path.exists(path):
+    ix = _native.NativeIndex.load(path)
+else:
+    from seismic_amd._abi import BuildConfig
+    ix = _native.NativeIndex.build(2, 30000, *docs, BuildConfig.defaults(n_postings=2000, centroid_fraction=0.2, summary_energy=0.5,
+                                                                          max_fraction=6.0, use_device=1))
+    ix.save(path)
 ix.upload(0)
 NQ=5000
 q_off, qc, qv = _native.synth(NQ, 30000, 43, 1, docs)
