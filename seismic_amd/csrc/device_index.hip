@@ -685,6 +685,14 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
     // LK_HASH seeds: the first multiplier of the family that sends the query's components to distinct slots
     // (component ids below 2^24; a query may fill at most a quarter of the table)
     pl.hash_ok = d->view.dim < (1u << 24) && !env_u32("SGPU_NO_HASH", 0);
+    if (pl.hash_ok && d->comp_width == 2 && d->view.dim <= 40000 && !env_u32("SGPU_FORCE_HASH", 0) && !env_u32("SGPU_NO_DENSE", 0)) {
+      // u16 components, a vocabulary whose dense byte table fits next to a second workgroup per CU: that table
+      // serves the batch (configure prefers it) unless a query has more than 255 components - the seeds (a
+      // millisecond of host time per 10 000 queries) are then not needed
+      bool dense_serves = true;
+      for (uint32_t q = 0; q < nq && dense_serves; ++q) dense_serves = h_off[q + 1] - h_off[q] <= 255;
+      if (dense_serves) pl.hash_ok = false;
+    }
     if (pl.hash_ok) {
       std::vector<uint32_t> stamp(kHashSlots, 0xffffffffu);
       uint32_t epoch = 0;
