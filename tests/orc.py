@@ -217,6 +217,21 @@ def quantize(values):
     return mn.value, qt.value, codes
 
 
+def interleave_index(desc):
+    """Spread the index's pages over the host's NUMA nodes; number of nodes used (0 = one node, or refused)."""
+    lib().orc_interleave_index.restype = C.c_int
+    lib().orc_interleave_index.argtypes = [C.POINTER(IndexDesc)]
+    return int(lib().orc_interleave_index(C.byref(desc)))
+
+
+def pin_plan(nt):
+    """(physical cores seen, the CPU each of nt pinned threads of the tuned batch search gets)."""
+    cpus = np.zeros(nt, np.int32)
+    lib().orc_pin_plan.restype = C.c_int
+    lib().orc_pin_plan.argtypes = [C.c_uint32, C.c_void_p]
+    return int(lib().orc_pin_plan(nt, _p(cpus))), cpus
+
+
 def score_doc_tuned(desc, doc, comps, vals):
     comps = np.ascontiguousarray(comps, np.uint32)
     vals = np.ascontiguousarray(vals, np.float32)
