@@ -338,7 +338,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
   if (!offsets || offsets[0] != 0) return fail(SGPU_EINVAL, "offsets[0] != 0");
   const uint64_t nnz = offsets[n_docs];
 #ifdef _OPENMP
-  const int nt = cfg.num_threads ? (int)cfg.num_threads : omp_get_max_threads();
+  const int nt = cfg.num_threads ? (int)cfg.num_threads : default_host_threads(omp_get_max_threads());
 #else
   const int nt = 1;
 #endif

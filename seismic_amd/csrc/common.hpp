@@ -14,6 +14,24 @@ namespace sgpu {
 std::string& last_error();
 sgpu_status fail(sgpu_status st, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// Threads a host-parallel phase uses when the caller passes num_threads == 0 ("all cores", the reference's rayon
+// default): the hardware threads this process may run on, capped by the container's CPU quota (cgroup cpu.max /
+// cfs_quota_us) - a team larger than the quota is descheduled for most of every accounting period. SGPU_HOST_THREADS
+// overrides.
+int default_host_threads(int omp_max_threads);
+}  // namespace sgpu
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+namespace sgpu {
+inline int host_threads() {
+#ifdef _OPENMP
+  return default_host_threads(omp_get_max_threads());
+#else
+  return 1;
+#endif
+}
+
 // ---- binary16 (document values are half::f16 in the reference:
 // src/index_traits.rs:57-142) ---------------------------------------------
 inline float f16_to_f32(uint16_t h) {

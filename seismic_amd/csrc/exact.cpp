@@ -30,7 +30,7 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
     if (vst != SGPU_OK) return vst;
   }
 #ifdef _OPENMP
-  const int nt = num_threads ? (int)num_threads : omp_get_max_threads();
+  const int nt = num_threads ? (int)num_threads : default_host_threads(omp_get_max_threads());
 #else
   const int nt = 1;
 #endif

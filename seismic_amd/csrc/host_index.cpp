@@ -13,6 +13,41 @@
 
 namespace sgpu {
 
+static double cgroup_cpu_quota() {   // CPUs' worth of time per period, 0 = none
+  double q = 0, per = 0;
+  char word[32] = {0};
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "max 100000" or "1600000 100000"
+    const int n = std::fscanf(f, "%31s %lf", word, &per);
+    std::fclose(f);
+    if (n == 2 && per > 0 && std::strcmp(word, "max") != 0) return std::atof(word) / per;
+    if (n == 2) return 0;
+  }
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // v1
+    const int n = std::fscanf(f, "%lf", &q);
+    std::fclose(f);
+    if (n == 1 && q > 0) {
+      if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        const int m = std::fscanf(g, "%lf", &per);
+        std::fclose(g);
+        if (m == 1 && per > 0) return q / per;
+      }
+    }
+  }
+  return 0;
+}
+int default_host_threads(int omp_max_threads) {
+  if (const char* e = std::getenv("SGPU_HOST_THREADS")) {
+    const int v = std::atoi(e);
+    if (v > 0) return v;
+  }
+  int nt = omp_max_threads > 0 ? omp_max_threads : 1;
+  static const double quota = cgroup_cpu_quota();
+  if (quota > 0) {
+    const int cap = (int)(quota + 0.999);
+    if (cap >= 1 && cap < nt) nt = cap;
+  }
+  return nt;
+}
 std::string& last_error() {
   static thread_local std::string e;
   return e;
@@ -328,7 +363,7 @@ sgpu_status host_index_convert(const HostIndex& src, uint32_t value_type, HostIn
       h.fwd_codes.resize(nnz);
       h.fwd_vals.clear();
       h.fwd_vals.shrink_to_fit();
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
       for (int64_t i = 0; i < (int64_t)nnz; ++i) {
         const float r = std::round(src.val((uint64_t)i) / step);   // exact division (power of two); half away from zero
         h.fwd_codes[(size_t)i] = r >= 255.0f ? 255 : (r > 0.0f ? (uint8_t)r : 0);

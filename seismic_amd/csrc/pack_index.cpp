@@ -35,7 +35,7 @@ void pack_records(const HostIndex& h, const std::vector<uint64_t>& rec_off16, st
   const uint32_t cw = h.comp_width, vb = h.val_bytes();
   std::vector<uint8_t>& fwd = *out;
   fwd.assign(std::max<uint64_t>(rec_off16[h.n_docs] * 16, 16), 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
   for (int64_t doc = 0; doc < (int64_t)h.n_docs; ++doc) {
     const uint64_t s0 = h.fwd_offsets[(size_t)doc], len = h.fwd_offsets[(size_t)doc + 1] - s0;
     const uint64_t npad = (len + 7) & ~7ull;
@@ -57,7 +57,7 @@ void pack_block_sizes(const HostIndex& h, std::vector<uint64_t>* out) {
   const uint64_t nb = h.n_blocks();
   std::vector<uint64_t>& bsize = *out;
   bsize.assign(nb + 1, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
   for (int64_t b = 0; b < (int64_t)nb; ++b) {
     uint64_t u = 0;
     for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
@@ -79,7 +79,7 @@ void pack_post_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, 
   const uint64_t nb = h.n_blocks();
   std::vector<uint64_t>& pref = *out;
   pref.assign(h.n_postings(), 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
   for (int64_t b = 0; b < (int64_t)nb; ++b) {
     uint64_t cur = blk_base + bsize[(size_t)b];
     for (int cls = 0; cls < 2; ++cls)
@@ -96,7 +96,7 @@ void pack_post_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, 
 void pack_doc_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, std::vector<uint64_t>* out) {
   std::vector<uint64_t>& dref = *out;
   dref.assign(h.n_docs, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
   for (int64_t doc = 0; doc < (int64_t)h.n_docs; ++doc)
     dref[(size_t)doc] = (rec_off16[(size_t)doc] << 16) | (h.fwd_offsets[(size_t)doc + 1] - h.fwd_offsets[(size_t)doc]);
 }
@@ -104,7 +104,7 @@ void pack_doc_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, s
 void pack_narrow(const std::vector<uint64_t>& v, std::vector<uint32_t>* out) {
   std::vector<uint32_t>& o = *out;
   o.assign(v.size(), 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
   for (int64_t i = 0; i < (int64_t)v.size(); ++i) o[(size_t)i] = (uint32_t)v[(size_t)i];
 }
 
@@ -113,7 +113,7 @@ void pack_narrow(const std::vector<uint64_t>& v, std::vector<uint32_t>* out) {
 void pack_row_mid(const HostIndex& h, std::vector<uint16_t>* out) {
   std::vector<uint16_t>& mid = *out;
   mid.assign(h.n_rows(), 0);
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(sgpu::host_threads())
   for (int64_t c = 0; c < (int64_t)h.dim; ++c) {
     const uint64_t nb = h.list_block_start[(size_t)c + 1] - h.list_block_start[(size_t)c];
     const uint16_t half = (uint16_t)((nb + 1) / 2);
@@ -130,7 +130,7 @@ void pack_row_mid(const HostIndex& h, std::vector<uint16_t>* out) {
 void pack_sum_deq(const HostIndex& h, std::vector<float>* out) {
   std::vector<float>& deq = *out;
   deq.assign(h.n_entries(), 0.0f);
-#pragma omp parallel for schedule(dynamic, 64)
+#pragma omp parallel for schedule(dynamic, 64) num_threads(sgpu::host_threads())
   for (int64_t c = 0; c < (int64_t)h.dim; ++c) {
     const uint64_t b0 = h.list_block_start[(size_t)c];
     for (uint64_t r = h.list_row_start[(size_t)c]; r < h.list_row_start[(size_t)c + 1]; ++r)

@@ -117,7 +117,7 @@ extern "C" sgpu_status sgpu_synth_generate(const sgpu_synth_spec* spec, const ui
   if (write && (!out_offsets || !out_vals)) return fail(SGPU_EINVAL, "null output arrays");
   // pass 1: sizes (every vector has its own stream, so this is cheap and the fill is parallel)
   std::vector<uint64_t> off(spec->n_vecs + 1, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
   for (int64_t i = 0; i < (int64_t)spec->n_vecs; ++i) {
     SplitMix64 rng(mix_seed(spec->seed, (uint64_t)i));
     off[(size_t)i + 1] = draw_nnz(rng, spec->kind, dim);
@@ -133,7 +133,7 @@ extern "C" sgpu_status sgpu_synth_generate(const sgpu_synth_spec* spec, const ui
   std::vector<float> tscale;
   make_topics(dim, n_topics, z, ttok, tscale);
 
-#pragma omp parallel
+#pragma omp parallel num_threads(sgpu::host_threads())
   {
     std::vector<uint8_t> used(dim, 0);
     std::vector<std::pair<uint32_t, float>> cur;

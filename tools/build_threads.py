@@ -1,11 +1,16 @@
-"""Host build time against the number of host threads (SGPU_DEBUG=1 prints the phases)."""
+"""Host build time against the number of host threads: the default (hardware threads capped by the container's CPU quota,
+common.hpp host_threads) against explicit counts.   python tools/build_threads.py [n_docs] [counts, e.g. 0,256,64,16]"""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from seismic_amd import _native
 from seismic_amd._abi import BuildConfig
-docs = _native.synth(2_000_000, 30000, 42, 0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+counts = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 256, 64, 16]
+t = time.time()
+docs = _native.synth(n, 30000, 42, 0)
+print("synth %d documents: %.1f s" % (n, time.time() - t), flush=True)
 cfg = dict(n_postings=2000, centroid_fraction=0.2, summary_energy=0.5, max_fraction=6.0, use_device=1)
-for nt in (256, 128, 64, 32):
+for nt in counts:
     t = time.time()
     _native.NativeIndex.build(2, 30000, *docs, BuildConfig.defaults(num_threads=nt, **cfg))
-    print("threads", nt, "total %.1f s" % (time.time() - t), flush=True)
+    print("num_threads %3d%s: total %.1f s" % (nt, " (default)" if nt == 0 else "", time.time() - t), flush=True)
