@@ -375,3 +375,21 @@ def test_round_1_index_files_still_load(tmp_path):
     st = _native.lib().sgpu_dataset_read(os.fsencode(dp), ctypes.byref(n), ctypes.byref(nnz), o.ctypes.data_as(ctypes.c_void_p),
                                          c.ctypes.data_as(ctypes.c_void_p), None)
     assert st == 1      # SGPU_EINVAL
+
+
+def test_default_host_thread_count_override_keeps_the_index(monkeypatch):
+    """num_threads == 0 takes the hardware threads capped by the container's CPU quota (common.hpp host_threads);
+    SGPU_HOST_THREADS overrides it. Whatever the team size, the index and the exact search are the same bytes."""
+    from util import desc_equal
+    dim = 300
+    off, comps, vals = random_dataset(11, 6000, dim, nnz_lo=5, nnz_hi=60)
+    base = _native.NativeIndex.build(2, dim, off, comps, vals, BuildConfig.defaults(n_postings=40))
+    q_off, qc, qv = random_queries(12, 16, dim, 5, 40)
+    ref = base.exact_search(q_off, qc, qv, 10)
+    for nt in ("1", "3", "13"):
+        monkeypatch.setenv("SGPU_HOST_THREADS", nt)
+        ix = _native.NativeIndex.build(2, dim, off, comps, vals, BuildConfig.defaults(n_postings=40))
+        desc_equal(base.desc, ix.desc)
+        got = ix.exact_search(q_off, qc, qv, 10)
+        for a, b in zip(ref, got):
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
