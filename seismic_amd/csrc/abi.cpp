@@ -21,6 +21,7 @@ void device_index_free(DeviceIndex* d);
 uint64_t device_index_bytes(const DeviceIndex* d);
 Lane* lane_acquire(DeviceIndex* d);
 Lane* lane_try_acquire(DeviceIndex* d);
+uint32_t coop_auto_max_queries(const DeviceIndex* d);
 void lane_release(DeviceIndex* d, Lane* l);
 Lane* lane_main(DeviceIndex* d);
 sgpu_batch** lane_scratch(Lane* l);
@@ -291,7 +292,10 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
                                 float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n) {
   static const uint32_t chunk_min = [] {
     const char* v = std::getenv("SGPU_CHUNK_MIN");
-    return v && *v ? (uint32_t)std::strtoul(v, nullptr, 10) : 2048u;
+    // (600 since r03: a 1250-query call - one rank's shard of a 10 000-query batch on eight GPUs - takes 1115 us in two
+    // chunks against 1260 in one, a 2500-query call 1.94 against 2.35 ms: the host side of a chunk, ~0.3 us per query,
+    // hides behind the previous chunk's kernel; chunks of ~300 lose to their launch tails. profiles/r03_chunk_probe.txt)
+    return v && *v ? (uint32_t)std::strtoul(v, nullptr, 10) : 600u;
   }();
   struct Job {
     Lane* lane;
@@ -305,6 +309,20 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
   Job jobs[8];
   uint32_t n_jobs = 1;
   if (chunk_min && nq >= 2 * chunk_min) n_jobs = std::min<uint32_t>(chunk_max, nq / chunk_min);
+  // Mid-size shards (more queries than the cooperative variant takes on its own, fewer than two chunks): the last
+  // `tail` queries go out as a second launch on another lane. It is small enough for the cooperative variant, its
+  // workgroups become resident as the first launch's run out of queries, and they then share the tail's work - the
+  // first launch's queries do not carry the cooperative variant's cost. SGPU_TAIL_COOP = queries in the tail, 0 = off.
+  uint32_t tail = 0;
+  if (n_jobs == 1) {
+    const char* tv = std::getenv("SGPU_TAIL_COOP");
+    const uint32_t want = tv && *tv ? (uint32_t)std::strtoul(tv, nullptr, 10) : 0u;
+    const uint32_t cmax = coop_auto_max_queries(d);
+    if (want && cmax && nq > cmax + std::min(want, cmax) && 2 * std::min(want, cmax) < nq) {
+      tail = std::min(want, cmax);
+      n_jobs = 2;
+    }
+  }
   std::vector<uint64_t> off;   // a chunk's offsets, rebased (sized here: nothing below allocates host memory)
   if (n_jobs > 1) {
     try {
@@ -321,6 +339,7 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
       break;
     }
   }
+  if (n_jobs < 2) tail = 0;
   const uint32_t k = params.k;
   sgpu_status st = SGPU_OK;
   std::string msg;
@@ -334,8 +353,12 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
     Job& jb = jobs[j];
     jb.q0 = (uint32_t)((uint64_t)nq * j / n_jobs);
     jb.q1 = (uint32_t)((uint64_t)nq * (j + 1) / n_jobs);
+    if (tail) {   // (two jobs: everything but the tail, then the tail)
+      jb.q0 = j == 0 ? 0 : nq - tail;
+      jb.q1 = j == 0 ? nq - tail : nq;
+    }
     const uint64_t* qo = q_off;
-    if (n_jobs > 1) {
+    if (n_jobs > 1 && jb.q0 != 0) {   // (a chunk that starts at query 0 uses the caller's offsets as they are)
       for (uint32_t q = jb.q0; q <= jb.q1; ++q) off[q - jb.q0] = q_off[q] - q_off[jb.q0];
       qo = off.data();
     }

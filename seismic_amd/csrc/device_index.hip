@@ -140,6 +140,14 @@ Lane* lane_acquire(DeviceIndex* d) {
   }
 }
 
+// Largest launch the cooperative kernel variant is chosen for on its own (configure); 0 = switched off.
+uint32_t coop_auto_max_queries(const DeviceIndex* d) {
+  const char* cm = std::getenv("SGPU_COOP");
+  if (cm && !std::strcmp(cm, "0")) return 0;
+  const char* v = std::getenv("SGPU_COOP_MAX_NQ");
+  return v && *v ? (uint32_t)std::strtoul(v, nullptr, 10) : (uint32_t)d->n_cu;
+}
+
 // A free lane, or null: a call that already holds one lane never WAITS for another (two callers each
 // holding some lanes and waiting for more would deadlock).
 Lane* lane_try_acquire(DeviceIndex* d) {
