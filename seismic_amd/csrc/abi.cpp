@@ -281,6 +281,33 @@ sgpu_status sgpu_batch_fetch_stats(sgpu_index* idx, sgpu_batch* batch, uint32_t*
 
 void sgpu_batch_destroy(sgpu_batch* batch) { batch_free(batch); }
 
+// How a shard of nq queries is cut (pure: tests/test_abi_and_host.py checks it through sgpu_debug_chunk_plan).
+// chunk_jobs: the number of launches wanted before lanes are taken; *tail > 0 means "everything but the last *tail
+// queries, then those" (SGPU_TAIL_COOP, two launches). chunk_bounds: the queries [q0, q1) of launch j of n_jobs.
+static uint32_t chunk_jobs(uint32_t nq, uint32_t chunk_min, uint32_t chunk_max, uint32_t want_tail, uint32_t coop_max,
+                           uint32_t* tail) {
+  uint32_t n_jobs = 1;
+  *tail = 0;
+  if (chunk_min && nq >= 2 * chunk_min) n_jobs = std::min<uint32_t>(chunk_max, nq / chunk_min);
+  if (n_jobs == 1 && want_tail && coop_max) {
+    const uint32_t t = std::min(want_tail, coop_max);
+    if (nq > coop_max + t && 2 * t < nq) {
+      *tail = t;
+      n_jobs = 2;
+    }
+  }
+  return n_jobs;
+}
+static void chunk_bounds(uint32_t nq, uint32_t n_jobs, uint32_t tail, uint32_t j, uint32_t* q0, uint32_t* q1) {
+  if (tail && n_jobs == 2) {
+    *q0 = j == 0 ? 0 : nq - tail;
+    *q1 = j == 0 ? nq - tail : nq;
+    return;
+  }
+  *q0 = (uint32_t)((uint64_t)nq * j / n_jobs);
+  *q1 = (uint32_t)((uint64_t)nq * (j + 1) / n_jobs);
+}
+
 // One shard of a batch on one replica: borrow a lane (its stream and recycled device batch), H2D of
 // the queries, one kernel pass, D2H of the results. No allocation once the lane's batch has grown to
 // the call's size; calls from different host threads take different lanes and overlap.
@@ -307,21 +334,16 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
     return n < 1 ? 1u : (n > 8 ? 8u : n);
   }();
   Job jobs[8];
-  uint32_t n_jobs = 1;
-  if (chunk_min && nq >= 2 * chunk_min) n_jobs = std::min<uint32_t>(chunk_max, nq / chunk_min);
-  // Mid-size shards (more queries than the cooperative variant takes on its own, fewer than two chunks): the last
-  // `tail` queries go out as a second launch on another lane. It is small enough for the cooperative variant, its
-  // workgroups become resident as the first launch's run out of queries, and they then share the tail's work - the
-  // first launch's queries do not carry the cooperative variant's cost. SGPU_TAIL_COOP = queries in the tail, 0 = off.
+  // Mid-size shards (SGPU_TAIL_COOP = n, an experiment, off by default): more queries than the cooperative variant takes
+  // on its own, fewer than two chunks - the last n queries go out as a second launch on another lane, small enough for
+  // the cooperative variant; its workgroups become resident as the first launch's run out of queries. Measured 7 %
+  // slower than one launch (profiles/r03_chunk_probe.txt).
   uint32_t tail = 0;
-  if (n_jobs == 1) {
+  uint32_t n_jobs;
+  {
     const char* tv = std::getenv("SGPU_TAIL_COOP");
     const uint32_t want = tv && *tv ? (uint32_t)std::strtoul(tv, nullptr, 10) : 0u;
-    const uint32_t cmax = coop_auto_max_queries(d);
-    if (want && cmax && nq > cmax + std::min(want, cmax) && 2 * std::min(want, cmax) < nq) {
-      tail = std::min(want, cmax);
-      n_jobs = 2;
-    }
+    n_jobs = chunk_jobs(nq, chunk_min, chunk_max, want, want ? coop_auto_max_queries(d) : 0u, &tail);
   }
   std::vector<uint64_t> off;   // a chunk's offsets, rebased (sized here: nothing below allocates host memory)
   if (n_jobs > 1) {
@@ -351,12 +373,7 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
   }
   for (uint32_t j = 0; j < n_jobs && st == SGPU_OK; ++j) {
     Job& jb = jobs[j];
-    jb.q0 = (uint32_t)((uint64_t)nq * j / n_jobs);
-    jb.q1 = (uint32_t)((uint64_t)nq * (j + 1) / n_jobs);
-    if (tail) {   // (two jobs: everything but the tail, then the tail)
-      jb.q0 = j == 0 ? 0 : nq - tail;
-      jb.q1 = j == 0 ? nq - tail : nq;
-    }
+    chunk_bounds(nq, n_jobs, tail, j, &jb.q0, &jb.q1);
     const uint64_t* qo = q_off;
     if (n_jobs > 1 && jb.q0 != 0) {   // (a chunk that starts at query 0 uses the caller's offsets as they are)
       for (uint32_t q = jb.q0; q <= jb.q1; ++q) off[q - jb.q0] = q_off[q] - q_off[jb.q0];
@@ -483,6 +500,18 @@ sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const
   if (breakdown_us)
     for (int i = 0; i < 8; ++i) breakdown_us[i] = nq ? phases[i] / nq : 0.0;
   return st;
+}
+
+// (not part of the boundary: how search_shard would cut a call of nq queries when `lanes_free` lanes can be had -
+// bounds[2 * j], bounds[2 * j + 1] = the queries [q0, q1) of launch j; returns the number of launches)
+uint32_t sgpu_debug_chunk_plan(uint32_t nq, uint32_t chunk_min, uint32_t chunk_max, uint32_t want_tail, uint32_t coop_max,
+                               uint32_t lanes_free, uint32_t* bounds) {
+  uint32_t tail = 0;
+  uint32_t n_jobs = chunk_jobs(nq, chunk_min, chunk_max < 1 ? 1 : (chunk_max > 8 ? 8 : chunk_max), want_tail, coop_max, &tail);
+  if (lanes_free >= 1 && n_jobs > lanes_free) n_jobs = lanes_free;
+  if (n_jobs < 2) tail = 0;
+  for (uint32_t j = 0; j < n_jobs; ++j) chunk_bounds(nq, n_jobs, tail, j, bounds + 2 * j, bounds + 2 * j + 1);
+  return n_jobs;
 }
 
 // (not part of the boundary: the timeline of a cooperative launch, for tools/coop_trace.py on a trace build)

@@ -393,3 +393,34 @@ def test_default_host_thread_count_override_keeps_the_index(monkeypatch):
         got = ix.exact_search(q_off, qc, qv, 10)
         for a, b in zip(ref, got):
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+
+
+def test_chunk_plan_of_a_call_covers_every_query_once():
+    """How sgpu_batch_search cuts a call into launches (abi.cpp chunk_jobs / chunk_bounds, through the debug export):
+    whatever the sizes, the launches are contiguous, in order, non-empty and cover [0, nq) exactly once."""
+    L = ctypes.CDLL(_native.LIB_PATH)
+    L.sgpu_debug_chunk_plan.restype = ctypes.c_uint32
+    L.sgpu_debug_chunk_plan.argtypes = [ctypes.c_uint32] * 6 + [ctypes.POINTER(ctypes.c_uint32)]
+    bounds = (ctypes.c_uint32 * 16)()
+    sizes = list(range(0, 70)) + [255, 256, 257, 511, 599, 600, 1199, 1200, 1201, 1250, 1799, 1800, 2399, 2400, 2500, 4095,
+                                  4096, 4097, 9999, 10000, 65535, 1000003, 2**31 - 1, 2**32 - 1]
+    for nq in sizes:
+        for chunk_min, chunk_max in ((600, 4), (2048, 4), (1, 8), (0, 4), (300, 2)):
+            for want_tail, coop_max in ((0, 256), (256, 256), (64, 256), (300, 256), (128, 0)):
+                for lanes in (1, 2, 3, 8):
+                    n = L.sgpu_debug_chunk_plan(nq, chunk_min, chunk_max, want_tail, coop_max, lanes, bounds)
+                    assert 1 <= n <= min(8, lanes), (nq, chunk_min, chunk_max, want_tail, coop_max, lanes, n)
+                    b = [bounds[i] for i in range(2 * n)]
+                    assert b[0] == 0 and b[-1] == nq
+                    for j in range(n):
+                        assert b[2 * j] <= b[2 * j + 1]
+                        if n > 1:
+                            assert b[2 * j] < b[2 * j + 1]          # no empty launch once a call is cut
+                            assert b[2 * j + 1] - b[2 * j] <= nq // 2 + 1 or b[2 * j] == 0   # rebased offsets fit their buffer
+                        if j:
+                            assert b[2 * j] == b[2 * j - 1]
+    # the defaults: 1250 queries -> two launches, 10 000 -> four, 1000 -> one; the cooperative tail only when asked for
+    assert L.sgpu_debug_chunk_plan(1250, 600, 4, 0, 256, 8, bounds) == 2 and bounds[1] == 625
+    assert L.sgpu_debug_chunk_plan(10000, 600, 4, 0, 256, 8, bounds) == 4 and bounds[1] == 2500
+    assert L.sgpu_debug_chunk_plan(1000, 600, 4, 0, 256, 8, bounds) == 1
+    assert L.sgpu_debug_chunk_plan(1000, 600, 4, 256, 256, 8, bounds) == 2 and [bounds[i] for i in range(4)] == [0, 744, 744, 1000]
