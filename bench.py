@@ -118,16 +118,16 @@ def workload_key(args, world, scaling):
     return key if args.value_type == "f16" else key + " vt=" + args.value_type
 
 
-def cpu_quota():
+def cpu_quota(root="/sys/fs/cgroup"):
     """CPUs' worth of time per accounting period this container may use (cgroup v2 cpu.max, v1 cfs quota); None = no quota."""
     try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        q, per = open(os.path.join(root, "cpu.max")).read().split()[:2]
         return None if q == "max" else float(q) / float(per)
     except (OSError, ValueError):
         pass
     try:
-        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        q = float(open(os.path.join(root, "cpu", "cpu.cfs_quota_us")).read())
+        per = float(open(os.path.join(root, "cpu", "cpu.cfs_period_us")).read())
         return None if q <= 0 else q / per
     except (OSError, ValueError):
         return None

@@ -502,6 +502,9 @@ sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const
   return st;
 }
 
+// (not part of the boundary: the team size a host-parallel phase would take for num_threads == 0)
+uint32_t sgpu_debug_host_threads(void) { return (uint32_t)host_threads(); }
+
 // (not part of the boundary: how search_shard would cut a call of nq queries when `lanes_free` lanes can be had -
 // bounds[2 * j], bounds[2 * j + 1] = the queries [q0, q1) of launch j; returns the number of launches)
 uint32_t sgpu_debug_chunk_plan(uint32_t nq, uint32_t chunk_min, uint32_t chunk_max, uint32_t want_tail, uint32_t coop_max,

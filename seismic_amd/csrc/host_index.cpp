@@ -14,19 +14,22 @@
 namespace sgpu {
 
 static double cgroup_cpu_quota() {   // CPUs' worth of time per period, 0 = none
+  // (SGPU_CGROUP_ROOT: where the cgroup files are looked for - a test hook, tests/test_abi_and_host.py)
+  const char* root_env = std::getenv("SGPU_CGROUP_ROOT");
+  const std::string root = root_env && *root_env ? root_env : "/sys/fs/cgroup";
   double q = 0, per = 0;
   char word[32] = {0};
-  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "max 100000" or "1600000 100000"
+  if (FILE* f = std::fopen((root + "/cpu.max").c_str(), "r")) {   // cgroup v2: "max 100000" or "1600000 100000"
     const int n = std::fscanf(f, "%31s %lf", word, &per);
     std::fclose(f);
     if (n == 2 && per > 0 && std::strcmp(word, "max") != 0) return std::atof(word) / per;
     if (n == 2) return 0;
   }
-  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // v1
+  if (FILE* f = std::fopen((root + "/cpu/cpu.cfs_quota_us").c_str(), "r")) {   // v1
     const int n = std::fscanf(f, "%lf", &q);
     std::fclose(f);
     if (n == 1 && q > 0) {
-      if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (FILE* g = std::fopen((root + "/cpu/cpu.cfs_period_us").c_str(), "r")) {
         const int m = std::fscanf(g, "%lf", &per);
         std::fclose(g);
         if (m == 1 && per > 0) return q / per;
@@ -41,7 +44,7 @@ int default_host_threads(int omp_max_threads) {
     if (v > 0) return v;
   }
   int nt = omp_max_threads > 0 ? omp_max_threads : 1;
-  static const double quota = cgroup_cpu_quota();
+  const double quota = cgroup_cpu_quota();   // (two small files per host-parallel phase: read every time, a quota may change)
   if (quota > 0) {
     const int cap = (int)(quota + 0.999);
     if (cap >= 1 && cap < nt) nt = cap;

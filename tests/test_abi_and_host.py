@@ -424,3 +424,38 @@ def test_chunk_plan_of_a_call_covers_every_query_once():
     assert L.sgpu_debug_chunk_plan(10000, 600, 4, 0, 256, 8, bounds) == 4 and bounds[1] == 2500
     assert L.sgpu_debug_chunk_plan(1000, 600, 4, 0, 256, 8, bounds) == 1
     assert L.sgpu_debug_chunk_plan(1000, 600, 4, 256, 256, 8, bounds) == 2 and [bounds[i] for i in range(4)] == [0, 744, 744, 1000]
+
+
+def test_cpu_quota_of_the_container_caps_the_default_host_team(tmp_path, monkeypatch):
+    """cgroup v2 `cpu.max` / v1 `cfs_quota_us`: the library's default team size (num_threads == 0) and bench.py's CPU
+    baseline both stay within the quota; "max" / -1 / no files mean no quota."""
+    import importlib.util
+    L = ctypes.CDLL(_native.LIB_PATH)
+    L.sgpu_debug_host_threads.restype = ctypes.c_uint32
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.delenv("SGPU_HOST_THREADS", raising=False)
+    empty = tmp_path / "none"
+    empty.mkdir()
+    monkeypatch.setenv("SGPU_CGROUP_ROOT", str(empty))
+    free = L.sgpu_debug_host_threads()          # no quota: what OpenMP would take
+    assert free >= 1 and bench.cpu_quota(str(empty)) is None
+    v2 = tmp_path / "v2"
+    v2.mkdir()
+    for text, want in (("max 100000\n", None), ("300000 100000\n", 3.0), ("150000 100000\n", 1.5), ("1600000 100000\n", 16.0)):
+        (v2 / "cpu.max").write_text(text)
+        monkeypatch.setenv("SGPU_CGROUP_ROOT", str(v2))
+        assert bench.cpu_quota(str(v2)) == want
+        cap = free if want is None else min(free, int(want + 0.999))
+        assert L.sgpu_debug_host_threads() == cap, (text, free)
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    for text, want in (("-1\n", None), ("200000\n", 2.0)):
+        (v1 / "cpu" / "cpu.cfs_quota_us").write_text(text)
+        monkeypatch.setenv("SGPU_CGROUP_ROOT", str(v1))
+        assert bench.cpu_quota(str(v1)) == want
+        assert L.sgpu_debug_host_threads() == (free if want is None else min(free, 2))
+    monkeypatch.setenv("SGPU_HOST_THREADS", "5")   # the override wins over everything
+    assert L.sgpu_debug_host_threads() == 5
