@@ -281,3 +281,14 @@ def test_tuned_cpu_path_is_bit_identical_to_the_restatement(comp_width, fixedu8)
                 assert ref[3] == got[3]          # work counters / algorithmic bytes
     finally:
         orc.knn_attach(None, 0)
+
+
+def test_tuned_baseline_pin_plan_gives_every_thread_its_own_cpu():
+    """The tuned batch search pins thread t to pin_order[pin_slot(t)] (physical cores first): distinct, allowed CPUs for
+    every team size up to the CPUs this process may use."""
+    import os
+    allowed = sorted(os.sched_getaffinity(0))
+    for nt in sorted({1, 2, 3, len(allowed) // 2 or 1, len(allowed)}):
+        cores, cpus = orc.pin_plan(nt)
+        assert 1 <= cores <= len(allowed)
+        assert len(set(cpus.tolist())) == nt and set(cpus.tolist()) <= set(allowed)
