@@ -66,6 +66,7 @@ struct Lane {
   uint8_t* coop = nullptr;         // board of the cooperative kernel variant (CoopView), all zero between launches
   size_t coop_bytes = 0, coop_trace_off = 0;
   uint32_t coop_trace_n = 0;
+  bool coop_last = false;          // the lane's last launch was a cooperative one (its board's error word is then checked)
   std::vector<hipEvent_t> ev0, ev1;   // timing of enqueued launches
   int ev_pending = 0;
   double sum_ms = 0;
@@ -93,6 +94,7 @@ struct DeviceIndex {
   uint32_t value_type = SGPU_VAL_F16;   // how the records store document values
   float val_scale = 0.0f;
   bool fwd_block_major = false;   // forward store holds a copy of every posting's record, block by block
+  bool coop_broken = false;       // a cooperative launch reported a protocol error: the variant stays off for this replica
   static constexpr int kMainEvents = 64, kPool = 8;   // two concurrent calls of four chunks each
   Lane main;
   Lane pool[kPool];
@@ -483,6 +485,8 @@ struct sgpu_batch {
   uint64_t* out_ids = nullptr;
   uint32_t* out_n = nullptr;
   uint32_t* out_stats = nullptr;   // nq x STATS_WORDS work counters of the last pass
+  uint32_t* status = nullptr;      // staged batches: the launch status word (BatchView::status) as the kernel addresses it
+  size_t status_off = 0;           //   ... and where it lies in the arena (the last 16 bytes of the input region)
   // Staged batches (the recycled batch of a pool lane, behind sgpu_search / sgpu_batch_search): every
   // device array above is a slice of ONE device arena mirrored by ONE pinned host buffer, so a call is
   // one H2D (work counter, queries, launch order), the kernel, one D2H (counts, scores, ids).
@@ -497,8 +501,42 @@ struct sgpu_batch {
 
 namespace sgpu {
 
-static uint32_t env_u32(const char* name, uint32_t dflt) {
+// Environment knobs (SGPU_*: experiments, tests, debugging aids) are looked at on the per-launch path; a getenv
+// walks the whole environment, and a launch reads some forty of them. They are therefore cached per thread
+// and keyed by a fingerprint of the environment (the pointers of `environ`: setenv / unsetenv replace an
+// entry's pointer, which is what Python's os.environ and the test suite's monkeypatch do), taken once per call
+// (env_refresh): ~0.1 us per launch instead of ~4 (r03: configure + launch 6.6 us of a 148 us single query).
+// A putenv() of a buffer edited in place is not noticed - these are not product switches.
+}  // namespace sgpu
+extern char** environ;
+namespace sgpu {
+struct EnvCache {
+  uint64_t fp = 0;
+  int n = 0;
+  struct E {
+    const char* name;
+    const char* val;
+  } e[96];
+};
+static thread_local EnvCache tl_env;
+static void env_refresh() {
+  uint64_t h = 1469598103934665603ull;
+  for (char** p = environ; p && *p; ++p) h = (h ^ (uint64_t)(uintptr_t)*p) * 1099511628211ull;
+  if (h != tl_env.fp || tl_env.n == 0) {
+    tl_env.fp = h;
+    tl_env.n = 0;
+  }
+}
+static const char* env_get(const char* name) {   // `name` is a string literal: compared by address first
+  EnvCache& c = tl_env;
+  for (int i = 0; i < c.n; ++i)
+    if (c.e[i].name == name) return c.e[i].val;
   const char* v = std::getenv(name);
+  if (c.n < (int)(sizeof(c.e) / sizeof(c.e[0]))) c.e[c.n++] = EnvCache::E{name, v};
+  return v;
+}
+static uint32_t env_u32(const char* name, uint32_t dflt) {
+  const char* v = env_get(name);
   if (!v || !*v) return dflt;
   return (uint32_t)std::strtoul(v, nullptr, 10);
 }
@@ -544,7 +582,11 @@ static hipError_t wait_lane(hipStream_t s, uint32_t nq) {
       if (e == hipSuccess) return hipSuccess;
       if (e != hipErrorNotReady) return e;
       if (now_us() - t0 > spin_us) break;
+#if defined(__x86_64__) || defined(__i386__)
       __builtin_ia32_pause();
+#elif defined(__aarch64__)
+      asm volatile("yield");
+#endif
     }
   }
   return hipStreamSynchronize(s);
@@ -790,22 +832,33 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     o += up(((uint64_t)qn + 1) * 4);
   }
   L.sel = (uint32_t)o; o += up((6ull * qc + 1) * 4);
-  if (o + up((uint64_t)qc * qn * 8) > lds_limit)
+  const uint64_t target = env_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
+  // what the layout needs besides the row tables and the block dots (the dense lookup table where it may be used)
+  const uint64_t rest = up((sp.first_sorted && searching) ? (uint64_t)sort_nb * 2 : 0) + up(2 * (NT / 64 + 1) * 4) +
+                        up((uint64_t)heap_variant(sp.k) * 64 * 8) +
+                        up(kStateWords * 4) +
+                        ((d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255) ? up((uint64_t)d->view.dim + 1)
+                                                                                           : up((uint64_t)words * 6)) +
+                        up(512 * 16 + NT * 12);
+  // Row tables of stage 1 (matched rows of every (list, query component) pair): for all of a query's lists when
+  // that - and all their block dots - fits next to everything else at 2 workgroups per CU (the benchmark
+  // configurations); otherwise the lists are walked in GROUPS of at most qg lists and the tables hold one group
+  // (r03 sized them for all lists: query_cut 16 x 96 query components = 29 KB, which cost the dense lookup table
+  // - the 0.95-recall operating point ran the packed lookup at 0.55 of peak). Four lists keep all eight
+  // wavefronts of stage 1 busy (two per list), so groups do not go below four unless asked (SGPU_LIST_GROUP).
+  auto rt_bytes = [&](uint64_t g) { return up(g * qn * 8) + up(g * qn * 2) + up(2ull * g * (qn + 1) * 4); };
+  uint32_t qg = qc;
+  if (pl && qc > 4 && o + rt_bytes(qc) + rest + (uint64_t)dots_cap * 4 > target) qg = 4;
+  qg = std::max<uint32_t>(1, std::min<uint32_t>(qg, env_u32("SGPU_LIST_GROUP", qc)));
+  if (o + rt_bytes(qg) > lds_limit)
     return fail(SGPU_ELIMIT, "query_cut %u x %u query components do not fit the row tables in LDS", qc, qn);
-  L.rt_start = (uint32_t)o; o += up((uint64_t)qc * qn * 8);
-  L.rt_mid = (uint32_t)o; o += up((uint64_t)qc * qn * 2);
-  L.rt_pre = (uint32_t)o; o += up(2ull * qc * (qn + 1) * 4);   // two streams (block-id halves) per list
+  L.rt_start = (uint32_t)o; o += up((uint64_t)qg * qn * 8);
+  L.rt_mid = (uint32_t)o; o += up((uint64_t)qg * qn * 2);
+  L.rt_pre = (uint32_t)o; o += up(2ull * qg * (qn + 1) * 4);   // two streams (block-id halves) per list
   // Block dots: all of a query's lists at once when that fits next to everything else at 2 workgroups
   // per CU; otherwise the kernel walks the lists in groups and the area shrinks, down to the largest
   // single list (docs/Guidelines.md:44-70: query_cut 10 over lists of 3600 blocks is 144 KB at once).
   if (pl && (uint64_t)dots_cap * 4 > 24u * 1024u) {
-    const uint64_t target = env_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);
-    const uint64_t rest = up((sp.first_sorted && searching) ? (uint64_t)sort_nb * 2 : 0) + up(2 * (NT / 64 + 1) * 4) +
-                          up((uint64_t)heap_variant(sp.k) * 64 * 8) +
-                          up(kStateWords * 4) +
-                          ((d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255) ? up((uint64_t)d->view.dim + 1)
-                                                                                             : up((uint64_t)words * 6)) +
-                          up(512 * 16 + NT * 12);
     const uint64_t fit = target > o + rest ? (target - o - rest) / 4 : 0;
     dots_cap = (uint32_t)std::max<uint64_t>(pl->max_list_nb, std::min<uint64_t>(dots_cap, std::max<uint64_t>(fit, 6144)));
   }
@@ -838,7 +891,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   auto uni_for = [&](uint32_t items) { return up(std::max<uint64_t>((uint64_t)items * 16 + NT * 12, sort_bytes)); };
   const uint64_t smallest_lookup = (d->comp_width == 4) ? split_bytes : bitmap_bytes;
   const uint32_t want_items = items_max;
-  if (!std::getenv("SGPU_ITEMS_MAX")) {
+  if (!env_get("SGPU_ITEMS_MAX")) {
     const uint32_t want = items_max;
     if (dense_ok)   // the dense table is worth smaller rounds (down to 512 items)
       while (items_max > 512 && o + dense_bytes + uni_for(items_max) > budget) items_max -= 128;
@@ -868,7 +921,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   bool hashed = searching && hash_family && pl && pl->hash_ok && !env_u32("SGPU_NO_LPT", 0) && !env_u32("SGPU_NO_HASH", 0) &&
                 !env_u32("SGPU_FORCE_SPLIT", 0) && !env_u32("SGPU_FORCE_DENSE", 0) &&
                 (d->comp_width == 4 || !dense || env_u32("SGPU_FORCE_HASH", 0));
-  if (hashed && !std::getenv("SGPU_ITEMS_MAX") && !env_u32("SGPU_FORCE_HASH", 0)) {
+  if (hashed && !env_get("SGPU_ITEMS_MAX") && !env_u32("SGPU_FORCE_HASH", 0)) {
     uint32_t im = want_items;
     while (im > 512 && o + hash_bytes + uni_for(im) > budget) im -= 128;
     if (o + hash_bytes + uni_for(im) <= budget) items_max = im;
@@ -887,6 +940,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   o += uni;
   L.qc = qc;
   L.qn = qn;
+  L.qg = qg;
   a->lookup = lookup;
   if (o > lds_limit)
     return fail(SGPU_ELIMIT,
@@ -914,8 +968,8 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->block = NT;
   a->lds_bytes = (uint32_t)o;
   if (env_u32("SGPU_DEBUG", 0))
-    std::fprintf(stderr, "sgpu configure: NT %u lookup %u items_max %u dots_cap %u uni %llu lds %llu\n", NT, lookup,
-                 items_max, dots_cap, (unsigned long long)uni, (unsigned long long)o);
+    std::fprintf(stderr, "sgpu configure: NT %u lookup %u items_max %u dots_cap %u lists/group %u of %u uni %llu lds %llu\n", NT, lookup,
+                 items_max, dots_cap, qg, qc, (unsigned long long)uni, (unsigned long long)o);
   a->stream = lane->stream;
   a->qb.q_off = b->q_off;
   a->qb.q_comp = b->q_comp;
@@ -939,12 +993,13 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     a->qb.q_seed = b->q_order + b->nq;
   }
   a->qb.out_stats = mode != MODE_DOTS ? b->out_stats : nullptr;   // (null for staged batches: no work counters)
+  a->qb.status = b->staged ? b->status : nullptr;
   // cooperative variant wanted? (decided before the occupancy query: it is its own kernel symbol)
   a->coop = CoopView{};
   {
-    const char* cm = std::getenv("SGPU_COOP");
+    const char* cm = env_get("SGPU_COOP");
     const bool force = cm && !std::strcmp(cm, "force");
-    const bool off = cm && !std::strcmp(cm, "0");
+    const bool off = (cm && !std::strcmp(cm, "0")) || d->coop_broken;
     // (measured r03, 8.8M documents: 1 query 133 vs 200 us, 8: 147 vs 297, 64: 316 vs 412, 256: 431 vs 486;
     // from ~1000 queries per launch on the variant's own cost - 6 % slower rounds, idle workgroups kept
     // resident - outweighs what its tail help returns: 780 vs 742 us)
@@ -976,7 +1031,10 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   {
     const bool force = a->coop.enabled == 2;
     const uint64_t uni_bytes = a->lds_bytes - a->L.uni;
-    if (a->coop.enabled && grid > 512) a->coop.enabled = 0;   // (the open-round bitmap has 512 bits)
+    if (a->coop.enabled && grid > 512) {   // the open-round bitmap has 512 bits: the cooperative grid is capped there
+      if (env_u32("SGPU_DEBUG", 0)) std::fprintf(stderr, "sgpu coop: grid %u capped at 512 (board size)\n", grid);
+      grid = 512;
+    }
     if (a->coop.enabled) {
       CoopView& c = a->coop;
       c.max_pos = std::min<uint32_t>(65535u, std::max<uint32_t>(a->L.dots_cap, 1u));
@@ -1026,7 +1084,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     }
   }
   // latency-bound launches bootstrap the threshold with ONE local round before they go wide
-  if (a->coop.enabled && b->nq <= d->n_cu && !std::getenv("SGPU_ITEMS_INIT"))
+  if (a->coop.enabled && b->nq <= d->n_cu && !env_get("SGPU_ITEMS_INIT"))
     a->p.items_init = std::min<uint32_t>(a->p.items_max, std::max<uint32_t>(1, env_u32("SGPU_COOP_ITEMS_INIT", 128)));
   if (!a->coop.enabled) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
   a->grid = grid;
@@ -1050,6 +1108,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     a->bitmaps = lane->bitmaps;
   }
   a->queue = b->staged ? b->queue_dev : lane->queue;
+  lane->coop_last = a->coop.enabled != 0;
   return SGPU_OK;
 }
 
@@ -1064,15 +1123,24 @@ static void drain_events(Lane* l) {   // stream must be idle
   l->ev_pending = 0;
 }
 
-// SGPU_COOP_CHECK=1 (the test suite sets it): after a lane's work is waited for, read the cooperative
-// board's sticky error word - a bounded device-side wait that gave up - and fail the call loudly.
-static sgpu_status coop_check(Lane* lane) {
-  static const bool on = env_u32("SGPU_COOP_CHECK", 0) != 0;
-  if (!on || !lane->coop) return SGPU_OK;
+// A cooperative launch that met a protocol error (a bounded device-side wait that gave up, control words of the
+// wrong round) says so in its status word / the board's sticky word. EVERY cooperative launch is checked (r03 did
+// so only under SGPU_COOP_CHECK): the call fails loudly, the sticky word is cleared so that later calls are
+// judged on their own, and the variant stays off for this replica from then on (plain launches carry on).
+static sgpu_status coop_report(DeviceIndex* d, Lane* lane, uint32_t code) {
+  if (!code) return SGPU_OK;
+  if (lane->coop) (void)hipMemsetAsync(lane->coop + 64 + 12, 0, 4, lane->stream);
+  (void)hipStreamSynchronize(lane->stream);
+  if (!d->coop_broken) std::fprintf(stderr, "seismic_hip: cooperative search kernel reported protocol error %u on device %d; "
+                                            "the cooperative variant is switched off for this index replica\n", code, d->device);
+  d->coop_broken = true;
+  return fail(SGPU_EDEVICE, "cooperative search kernel: protocol wait gave up (code %u)", code);
+}
+static sgpu_status coop_check_board(DeviceIndex* d, Lane* lane) {   // device-resident batches (not the latency path)
+  if (!lane->coop || !lane->coop_last) return SGPU_OK;
   uint32_t flag = 0;
   HIP_TRY(hipMemcpy(&flag, lane->coop + 64 + 12, 4, hipMemcpyDeviceToHost));
-  if (flag) return fail(SGPU_EDEVICE, "cooperative search kernel: protocol wait gave up (code %u)", flag);
-  return SGPU_OK;
+  return coop_report(d, lane, flag);
 }
 
 // Enqueues one pass on `lane` (the index's main lane when null).
@@ -1086,6 +1154,7 @@ sgpu_status batch_run(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sgpu_sear
     if (stats) *stats = sgpu_launch_stats{};
     return SGPU_OK;
   }
+  env_refresh();
   {
     // configuration touches state shared by the lanes (occupancy cache, bitmaps); a main-lane
     // launch also owns the main lane's event ring
@@ -1158,7 +1227,7 @@ sgpu_status batch_fetch(DeviceIndex* d, Lane* lane, sgpu_batch* b, uint32_t k, f
   }
   HIP_TRY(hipMemcpyAsync(out_n, b->out_n, (size_t)b->nq * 4, hipMemcpyDeviceToHost, lane->stream));
   HIP_TRY(hipStreamSynchronize(lane->stream));
-  return coop_check(lane);
+  return coop_check_board(d, lane);
 }
 
 sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out) {
@@ -1201,14 +1270,17 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   if (sp.k > 1024) return fail(SGPU_ELIMIT, "k = %u exceeds the heap limit of 1024", sp.k);
   uint32_t max_nnz = 0;
   PhaseClock pc;
+  env_refresh();
   sgpu_status st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz, q_base);
   if (st != SGPU_OK) return st;
   HIP_TRY(hipSetDevice(d->device));
   const uint64_t nnz = q_off[nq];
   const uint32_t k = sp.k;
-  // arena: [work counter 16 B | q_off | q_comp | q_val | order]  ->  [out_n | out_scores | out_ids]
+  // arena: [work counter 16 B | q_off | q_comp | q_val | order | status 16 B]  ->  [status | out_n | out_scores | out_ids]
+  // (the status word goes down zeroed with the input and comes back with the rows)
   const size_t o_off = 16, o_comp = o_off + al16((size_t)(nq + 1) * 4), o_val = o_comp + al16(nnz * 4),
-               o_order = o_val + al16(nnz * 4), in_bytes = o_order + al16((size_t)nq * 8);   // [order | hash seeds]
+               o_order = o_val + al16(nnz * 4), o_status = o_order + al16((size_t)nq * 8),   // [order | hash seeds]
+               in_bytes = o_status + 16;
   const size_t r_n = in_bytes, r_sc = r_n + al16((size_t)nq * 4), r_id = r_sc + al16((size_t)nq * k * 4),
                total = r_id + al16((size_t)nq * k * 8);
   sgpu_batch* b = *slot;
@@ -1240,6 +1312,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   b->in_bytes = in_bytes;
   b->out_off = r_n;
   b->out_bytes = total - r_n;
+  b->status_off = o_status;
   if (nq == 0) return SGPU_OK;
   const uint32_t qn = std::max<uint32_t>(4, (max_nnz + 3u) & ~3u);
   const uint32_t cut = std::min<uint32_t>(sp.query_cut, qn);
@@ -1261,6 +1334,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     std::memcpy(hs + o_val, vals, nnz * 4);
   }
   std::memcpy(hs + o_order, b->plans.back().order.data(), (size_t)nq * 8);
+  std::memset(hs + o_status, 0, 16);
   b->queue_dev = (uint32_t*)b->arena_dev;
   b->q_off = (uint32_t*)(b->arena_dev + o_off);
   b->q_comp = (uint32_t*)(b->arena_dev + o_comp);
@@ -1277,6 +1351,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   b->out_scores = (float*)(out_base + r_sc);
   b->out_ids = (uint64_t*)(out_base + r_id);
   b->out_stats = nullptr;
+  b->status = (uint32_t*)(out_base + o_status);
   pc.lap(1);
   HIP_TRY(hipMemcpyAsync(b->arena_dev, hs, in_bytes, hipMemcpyHostToDevice, lane->stream));
   pc.lap(2);
@@ -1290,7 +1365,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   }
   pc.lap(3);
   if (st == SGPU_OK && he == hipSuccess && !b->direct_out)
-    he = hipMemcpyAsync(hs + r_n, b->arena_dev + r_n, b->out_bytes, hipMemcpyDeviceToHost, lane->stream);
+    he = hipMemcpyAsync(hs + o_status, b->arena_dev + o_status, 16 + b->out_bytes, hipMemcpyDeviceToHost, lane->stream);
   pc.lap(4);
   if (st != SGPU_OK || he != hipSuccess) {
     (void)hipStreamSynchronize(lane->stream);
@@ -1306,11 +1381,11 @@ sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_
   PhaseClock pc;
   HIP_TRY(wait_lane(lane->stream, b ? b->nq : 0));
   pc.lap(5);
-  {
-    const sgpu_status cs = coop_check(lane);
+  if (!b || b->nq == 0) return SGPU_OK;
+  if (lane->coop_last) {   // the launch's status word came back with the rows
+    const sgpu_status cs = coop_report(d, lane, *(const volatile uint32_t*)(b->arena_host + b->status_off));
     if (cs != SGPU_OK) return cs;
   }
-  if (!b || b->nq == 0) return SGPU_OK;
   const size_t nq = b->nq, k = b->k_max;
   const uint8_t* r = b->arena_host + b->out_off;
   std::memcpy(out_n, r, nq * 4);

@@ -44,6 +44,8 @@ struct BatchView {
   const uint32_t* q_order; // optional processing order (queue ticket -> query), longest expected first
   const uint32_t* q_seed;  // LK_HASH: per query, the seed of its collision-free hash multiplier
   uint32_t* out_stats;     // optional nq x STATS_WORDS counters (zeroed by the host before a pass)
+  uint32_t* status;        // optional launch status word (zero before the launch; the cooperative variant stores a
+                           //   protocol-error code here - it comes back to the host with the result rows)
 };
 
 enum { MODE_SEARCH = 0, MODE_DOTS = 1, MODE_COUNTED = 2 };   // COUNTED: search with the visited bitmap (exact counters)
@@ -82,10 +84,19 @@ enum { kStateWords = 160 };   // per-workgroup state words in LDS (ST_* in searc
 // All shared words are written and read with agent-scope (sc1) accesses; see search_kernel.inc.
 struct CoopView {
   uint64_t* open;       // [8] bit s: slot s has an open round with unclaimed positions (one 64-byte line)
-  uint32_t* counters;   // [0] idle workgroups [1] finished queries [2] exited workgroups [3] sticky protocol-error flag
-                        //   (a bounded wait gave up; checked by the host after every cooperative launch of a checked lane)
-  uint64_t* slots;      // per owner slot (blockIdx.x), kCoopSlotWords u64: [0] claim = seq:20 | end:22 | next:22
-                        //   [1] done:32 | -   [2] n_cand:32 | -   [3] query:32 | thr0:32   [4] cut:32 | seq:32
+  uint32_t* counters;   // [0] idle workgroups [1] finished queries [2] exited workgroups [3] sticky protocol-error code
+                        //   (1: an owner's wait for its chunks gave up, 2: a helper's wait for work gave up, 3: control
+                        //   words of another round than the claimed one); the host reads it after every cooperative launch
+  uint64_t* slots;      // per owner slot (blockIdx.x), kCoopSlotWords u64:
+                        //   [0] claim = next chunk:20 | positions of the round:22 | positions per chunk:10 | round:10
+                        //       (search_kernel.inc: co_claim_word; claimed with fetch_add(1) - round-independent)
+                        //   [1] done:32 (positions reported)   [2] n_cand:32   [3] query:32 | thr0:32   [4] cut:32 | round:32
+                        // Invariant between launches: open[] and counters[0..2] are zero (the last workgroup out
+                        // re-zeroes them and the slot words). Nothing else of the board needs to be: a slot's words
+                        // are rewritten in full BEFORE its open bit is set, and pos_pub / cands are only ever read
+                        // below the counts those words publish - so stale regions left by a launch with another
+                        // grid or max_pos are never interpreted. Keep it that way: no reader may touch a slot's
+                        // words before it has seen the slot's open bit (or holds a valid claim on it).
   uint64_t* pos_pub;    // [slots x max_pos] {dot bits : 32 | global block id : 32}, traversal order
   uint64_t* cands;      // [slots x max_cand x 2] {score bits:32 | key:32 (pos << 16 | posting in block)}, {bdot bits:32 | doc:32}
   uint32_t max_pos;     // positions per slot (<= 65535)
@@ -119,6 +130,7 @@ struct KParams {
 struct LdsLayout {   // byte offsets into dynamic LDS, all multiples of 16
   uint32_t q_comp, q_val, q_sc, q_bits, q_rank, sel, rt_start, rt_mid, rt_pre, dots, order, uni, part, heap, st;
   uint32_t qc, qn;   // capacities: lists per query, components per query
+  uint32_t qg;       // lists per GROUP (<= qc): the row tables of stage 1 (rt_*) hold this many lists
   uint32_t dots_cap; // block dots that fit the dots area: a query's lists are processed in groups of at most this many blocks
   uint32_t total;
 };

@@ -32,11 +32,12 @@ ap.add_argument("--centroid-fraction", type=float, default=0.2)
 ap.add_argument("--summary-energy", type=float, default=0.5)
 ap.add_argument("--max-fraction", type=float, default=6.0)
 ap.add_argument("--min-cluster-size", type=int, default=2)
+ap.add_argument("--no-save", action="store_true", help="do not cache the built index under /tmp")
 a = ap.parse_args()
 npost = a.n_postings or max(1, 2000 * a.docs // 1000000)
 docs = _native.synth(a.docs, a.dim, 42, 0)
 path = "/tmp/prof_%d_%d_%d_cw%d_cf%g.idx" % (a.docs, a.dim, npost, a.comp_width, a.centroid_fraction)
-if os.path.exists(path):
+if os.path.exists(path) and not a.no_save:
     ix = _native.NativeIndex.load(path)
 else:
     t = time.time()
@@ -44,7 +45,8 @@ else:
         n_postings=npost, centroid_fraction=a.centroid_fraction, summary_energy=a.summary_energy,
         max_fraction=a.max_fraction, min_cluster_size=a.min_cluster_size, use_device=1))
     print("build %.1fs" % (time.time() - t))
-    ix.save(path)
+    if not a.no_save:
+        ix.save(path)
 ix.upload(0)
 q = _native.synth(a.queries, a.dim, 43, 1, docs)
 b = _native.DeviceBatch(ix, *q, a.k)
