@@ -582,7 +582,7 @@ def main():
                                             and np.array_equal(lsc.view(np.uint32), gsc[:ns].view(np.uint32))),
             "reference_published_us": 185.0,   # README.md:110-115 (Core Ultra 7 265K, real MS MARCO; other data, other host)
         }
-        # the same calls one by one through the ctypes binding: three passes, the fastest one reported and all three kept -
+        # the same calls one by one through the ctypes binding: three passes, the median reported and all three kept -
         # a pass that meets one scheduler stall of the container (the GPU boxes run under a 16-CPU cgroup quota; a
         # throttled period parks the process for tens of milliseconds) reads 200 us per call higher than its
         # neighbours (profiles/r03_binding_probe.txt: 153 / 352 / 148 us for identical passes)
@@ -594,7 +594,7 @@ def main():
                 index.search(s_comp[int(s_off[i]):int(s_off[i + 1])], s_val[int(s_off[i]):int(s_off[i + 1])], args.k,
                              args.query_cut, args.heap_factor, srt)
             py_passes.append((time.perf_counter() - t0) * 1e6 / max(nlat, 1))
-        out["latency"]["through_python_binding_us"] = min(py_passes)
+        out["latency"]["through_python_binding_us"] = float(np.median(py_passes))   # (median of the three passes)
         out["latency"]["through_python_binding_passes_us"] = py_passes
         singles = [_native.DeviceBatch(index, np.array([0, int(s_off[i + 1] - s_off[i])], np.uint64),
                                        s_comp[int(s_off[i]):int(s_off[i + 1])], s_val[int(s_off[i]):int(s_off[i + 1])], args.k)
@@ -618,63 +618,161 @@ def main():
         out["timing_s"]["exact_ground_truth"] = time.time() - t0
 
     if rank == 0 and world == 1 and exact_ids is not None and args.target_recall.strip():
-        # ---- operating points at fixed recall (the metric is "at fixed recall@10"): on THIS index, the cheapest
-        # (query_cut, heap_factor, first_sorted) whose recall@k on the sample reaches each target - what the
-        # reference's recall_90 ... recall_99 files are for real data (experiments/best_configs/**/recall_9*.toml:42-44).
-        # "Cheapest" = shortest kernel time of the sample launch. Each chosen point is then measured like the
-        # headline (whole batches: entry point, device-resident launches, counted pass) and checked against the oracle.
+        # ---- operating points at fixed recall (the metric is "at fixed recall@10") the way the reference makes them:
+        # a recall target is reached through INDEX parameters (n_postings, max_fraction) with a small query_cut, one
+        # index per target (experiments/best_configs/msmarco-v1/splade-v3/mem_budget_2.0/recall_90 ... recall_99.toml
+        # differ in n-postings 2000/3000/4000, max-fraction 2/3/4/6, query-cut 4/6, heap-factor 0.9/1.0). The index
+        # parameters per target come from profiles/operating_points.json - the cheapest of a sweep over index AND query
+        # parameters on this collection (tools/operating_sweep.py, a GPU run of minutes; committed with its raw points).
+        # Here every target's index is built, its query parameters are re-selected on THIS run's sample among the
+        # recorded point and its neighbours (cheapest whole-batch kernel time that reaches the target), and the point
+        # is measured like the headline: entry point, device-resident launches, counted pass -> roofline, single-query
+        # latency, results identical to the CPU oracle, and the CPU oracle timed at the same parameters.
         import orc
         t0 = time.time()
         targets = [float(x) for x in args.target_recall.split(",") if x.strip()]
-        sb = _native.DeviceBatch(index, s_off, s_comp, s_val, args.k)
-        grid_pts = []
-        for cut in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
-            for hf in (0.6, 0.7, 0.8, 0.9, 1.0):
-                for fs in (False, True):
-                    sb.run(args.k, cut, hf, fs)
-                    ms = min(sb.run(args.k, cut, hf, fs).kernel_ms for _ in range(2))
-                    _, pid, pn = sb.fetch(args.k)
-                    grid_pts.append({"query_cut": cut, "heap_factor": hf, "first_sorted": fs, "recall": recall_of(pid, pn), "sample_kernel_ms": ms})
-        del sb
+        try:
+            recorded = json.load(open(os.path.join(ROOT, "profiles", "operating_points.json")))
+        except (OSError, ValueError):
+            recorded = {"targets": []}
+        rec_by_t = {round(float(t_["target_recall"]), 4): t_ for t_ in recorded.get("targets", [])}
+        head_idx = {"n_postings": args.n_postings, "max_fraction": args.max_fraction,
+                    "centroid_fraction": args.centroid_fraction, "summary_energy": args.summary_energy}
+        quota = cpu_quota()
+        ncores = os.cpu_count() or 1
+        cpu_threads = ncores if quota is None else max(2, min(ncores, int(quota)))
         points = []
-        for tgt in targets:
-            ok = [g for g in grid_pts if g["recall"] >= tgt]
-            if not ok:
-                best = max(grid_pts, key=lambda g: g["recall"])
-                points.append({"target_recall": tgt, "reached": False, "best_recall_on_grid": best["recall"],
-                               "at": {k_: best[k_] for k_ in ("query_cut", "heap_factor", "first_sorted")}})
-                continue
-            g = min(ok, key=lambda g: g["sample_kernel_ms"])
-            cut, hf, fs = g["query_cut"], g["heap_factor"], g["first_sorted"]
+        built = {}   # index parameters -> (index, resident batches); at most one extra index is alive at a time
+
+        def index_for(ip):
+            key_ = json.dumps(ip, sort_keys=True)
+            if ip == head_idx:
+                return index, batches, 0.0, 0.0
+            if key_ in built:
+                return built[key_]
+            for v_ in list(built.values()):   # free the previous target's index before the next one is built
+                for b_ in v_[1]:
+                    b_.close()
+                v_[0].close()
+            built.clear()
+            t1 = time.time()
+            docs_ = _native.read_inner_format(args.documents) if args.documents else _native.synth(args.docs, args.dim, 42, 0)
+            cfg_ = BuildConfig.defaults(n_postings=int(ip["n_postings"]), centroid_fraction=float(ip["centroid_fraction"]),
+                                        summary_energy=float(ip["summary_energy"]), max_fraction=float(ip["max_fraction"]),
+                                        min_cluster_size=args.min_cluster_size, doc_cut=15,
+                                        use_device=0 if args.build_on_host else (local_rank + 1))
+            ix_ = _native.NativeIndex.build(args.comp_width, int(d.dim), *docs_, cfg_)
+            del docs_
+            tb_ = time.time() - t1
+            if args.value_type == "fixedu8":
+                ix_ = ix_.convert(1)
+            t1 = time.time()
+            ix_.upload(local_rank)
+            tu_ = time.time() - t1
             nb_ = min(5, n_batches)
-            sel = [(first + j) % n_batches for j in range(nb_)]   # batch `first` holds the sample
-            calls = [(lambda b_=b_: index.batch_search(*host_batches[b_], args.k, cut, hf, fs, out=outs[b_])) for b_ in sel]
+            bs_ = [_native.DeviceBatch(ix_, *host_batches[(first + j) % n_batches], args.k) for j in range(nb_)]
+            built[key_] = (ix_, bs_, tb_, tu_)
+            return built[key_]
+
+        def measure(ix_, bs_, cut, hf, fs):
+            """One (query_cut, heap_factor, first_sorted) on resident batch 0 of bs_ (it holds the sample): kernel ms of the
+            whole-batch launch (best of two) and recall@k of the sample rows."""
+            bs_[0].run(args.k, cut, hf, fs)
+            ms_ = min(bs_[0].run(args.k, cut, hf, fs).kernel_ms for _ in range(2))
+            _, pid_, pn_ = bs_[0].fetch(args.k)
+            return float(ms_), recall_of(pid_, pn_)
+
+        for tgt in targets:
+            rec = rec_by_t.get(round(tgt, 4))
+            if rec is None or not rec.get("reached", False):
+                points.append({"target_recall": tgt, "reached": False,
+                               "note": "no recorded operating point for this target (profiles/operating_points.json)"})
+                continue
+            ip = {k_: rec["best"]["index"][k_] for k_ in ("n_postings", "max_fraction", "centroid_fraction", "summary_energy")}
+            ix_, bs_, tb_, tu_ = index_for(ip)
+            same_index = ip == head_idx
+            if same_index:   # batch `first` holds the sample
+                bs_ = [batches[(first + j) % n_batches] for j in range(min(5, n_batches))]
+            # candidates: the recorded point and runners-up on the same index, plus their neighbours in query_cut / heap_factor
+            cands = set()
+            for r_ in [rec["best"]] + list(rec.get("runners_up", [])):
+                if {k_: r_["index"][k_] for k_ in ip} != ip:
+                    continue
+                for dc in (-1, 0, 1, 2):
+                    for hf_ in sorted({float(r_["heap_factor"]), 1.0, 0.9}):
+                        if int(r_["query_cut"]) + dc >= 1:
+                            cands.add((int(r_["query_cut"]) + dc, hf_, bool(r_["first_sorted"])))
+            tried = []
+            for cut, hf, fs in sorted(cands):
+                ms_, rc_ = measure(ix_, bs_, cut, hf, fs)
+                tried.append({"query_cut": cut, "heap_factor": hf, "first_sorted": fs, "recall": rc_, "batch_kernel_ms": ms_})
+            ok = [g for g in tried if g["recall"] >= tgt]
+            if not ok:
+                best = max(tried, key=lambda g: g["recall"])
+                points.append({"target_recall": tgt, "reached": False, "index": ip, "best_recall_tried": best["recall"],
+                               "at": {k_: best[k_] for k_ in ("query_cut", "heap_factor", "first_sorted")}, "tried": len(tried)})
+                continue
+            g = min(ok, key=lambda g: g["batch_kernel_ms"])
+            cut, hf, fs = g["query_cut"], g["heap_factor"], g["first_sorted"]
+            nb_ = len(bs_)
+            sel = [(first + j) % n_batches for j in range(nb_)]
+            calls = [(lambda b_=b_: ix_.batch_search(*host_batches[b_], args.k, cut, hf, fs, out=outs[b_])) for b_ in sel]
             run_calls(calls[:n_threads], n_threads)
             dt_e = run_calls(calls, n_threads)
-            batches[first].sync()   # (resets the library's running mean of kernel durations)
-            for b_ in sel:
-                batches[b_].run(args.k, cut, hf, fs, sync=False)
-            st_ = batches[first].sync()
-            batches[first].run_counted(args.k, cut, hf, fs)
-            ab, _ = batches[first].algorithmic_bytes(args.k, args.comp_width, 2 if args.value_type == "f16" else 1)
-            psc, pid, pn = batches[first].fetch(args.k)
-            osc, oid, on_, _, _, _ = orc.batch_search(d, s_off, s_comp, s_val, args.k, cut, hf, fs, tuned=True)
-            _, _, _, lat_us, _ = index.search_sequential(s_off[:min(ns, 300) + 1], s_comp, s_val, args.k, cut, hf, fs)
-            pt = {"target_recall": tgt, "reached": True, "query_cut": cut, "heap_factor": hf, "first_sorted": fs,
+            bs_[0].sync()   # (resets the library's running mean of kernel durations)
+            for b_ in bs_:
+                b_.run(args.k, cut, hf, fs, sync=False)
+            st_ = bs_[0].sync()
+            bs_[0].run_counted(args.k, cut, hf, fs)
+            ab, cst = bs_[0].algorithmic_bytes(args.k, args.comp_width, 2 if args.value_type == "f16" else 1)
+            psc, pid, pn = bs_[0].fetch(args.k)
+            dx = ix_.desc
+            osc, oid, on_, _, secs_1, _ = orc.batch_search(dx, s_off, s_comp, s_val, args.k, cut, hf, fs, num_threads=1, tuned=True)
+            best_n, used_n = 0.0, cpu_threads
+            if not args.no_cpu:
+                for rep in range(3):   # all-core: the quota-capped team, best of the second and third pass
+                    r_ = orc.batch_search(dx, s_off, s_comp, s_val, args.k, cut, hf, fs, num_threads=cpu_threads, tuned=True)
+                    if rep:
+                        best_n = max(best_n, ns / r_[4])
+                    used_n = int(r_[5])
+            _, _, _, lat_us, _ = ix_.search_sequential(s_off[:min(ns, 300) + 1], s_comp, s_val, args.k, cut, hf, fs)
+            pa = argparse.Namespace(**vars(args))
+            pa.n_postings, pa.max_fraction = int(ip["n_postings"]), float(ip["max_fraction"])
+            pa.centroid_fraction, pa.summary_energy = float(ip["centroid_fraction"]), float(ip["summary_energy"])
+            pa.query_cut, pa.heap_factor, pa.first_sorted = cut, hf, int(fs)
+            pkey = workload_key(pa, world, scaling)
+            ptraffic, pnote = recorded_traffic(pkey)
+            kms_ = float(st_.kernel_ms)
+            pt = {"target_recall": tgt, "reached": True, "index": dict(ip, hbm_bytes=ix_.device_bytes(), build_s=tb_, upload_s=tu_,
+                                                                      same_as_headline=same_index),
+                  "query_cut": cut, "heap_factor": hf, "first_sorted": fs,
                   "recall_at_k": g["recall"], "value": my_q * nb_ / dt_e, "unit": "queries/s",
-                  "device_resident_qps": my_q / (float(st_.kernel_ms) * 1e-3) if st_.kernel_ms > 0 else None,
-                  "kernel_ms": float(st_.kernel_ms), "mean_latency_us_single_query": lat_us,
-                  "roofline_frac": ab / (float(st_.kernel_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS if st_.kernel_ms > 0 else None,
-                  "algorithmic_bytes_per_launch": ab}
+                  "device_resident_qps": my_q / (kms_ * 1e-3) if kms_ > 0 else None,
+                  "kernel_ms": kms_, "mean_latency_us_single_query": lat_us,
+                  "roofline_frac": ab / (kms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS if kms_ > 0 else None,
+                  "algorithmic_bytes_per_launch": ab, "traffic": ptraffic, "traffic_note": pnote, "workload_key": pkey,
+                  "docs_scored_per_query": float(cst[:, 5].mean()), "launch": {"grid": int(st_.grid), "lds_bytes": int(st_.lds_bytes)},
+                  "candidates_tried": len(tried)}
             pt["identical_to_cpu_oracle_on_sample"] = bool(
                 np.array_equal(on_, pn[:ns]) and np.array_equal(oid, pid[:ns])
                 and np.array_equal(osc.view(np.uint32), psc[:ns].view(np.uint32)))
+            pt["cpu_baseline"] = {"single_thread_us_per_query": secs_1 * 1e6 / ns, "value": best_n if best_n > 0 else None,
+                                  "unit": "queries/s", "cores": used_n, "kind": "port",
+                                  "sample": "the %d sample queries at this point's parameters: one single-thread pass, "
+                                            "best of two passes on %d pinned threads" % (ns, used_n)}
+            if best_n > 0:
+                pt["gpu_over_cpu_allcore"] = pt["value"] / best_n
             points.append(pt)
+        for v_ in list(built.values()):
+            for b_ in v_[1]:
+                b_.close()
+            v_[0].close()
+        built.clear()
         out["operating_points"] = points
-        out["operating_points_grid"] = {"points": len(grid_pts), "query_cut": [1, 2, 3, 4, 5, 6, 8, 10, 12, 16],
-                                        "heap_factor": [0.6, 0.7, 0.8, 0.9, 1.0], "first_sorted": [False, True],
-                                        "recall_range": [min(g["recall"] for g in grid_pts), max(g["recall"] for g in grid_pts)],
-                                        "selection": "lowest kernel time of the %d-query sample launch among the grid points reaching the target" % ns}
+        out["operating_points_source"] = {
+            "file": "profiles/operating_points.json", "sweep": recorded.get("sweep"),
+            "selection": "per target the cheapest whole-batch kernel time among index AND query parameters (tools/operating_sweep.py); "
+                         "query parameters re-selected here on this run's %d-query sample among the recorded point and its neighbours" % ns}
         out["timing_s"]["operating_points"] = time.time() - t0
 
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -722,7 +820,9 @@ def main():
         out["cpu_baseline"] = {
             "value": qpsn, "unit": "queries/s", "cores": int(used), "kind": "port",
             "sample": "the first %d queries of the first timed batch: %d passes on %d pinned OpenMP threads (one query "
-                      "per task) after a thread-count sweep; single thread: fastest of 3 passes" % (ns, runs_n, used),
+                      "per task) after a thread-count sweep; single thread: fastest of 3 passes. The host has %d hardware "
+                      "threads; the container may use %s CPUs' worth of time (cgroup quota), which caps the team"
+                      % (ns, runs_n, used, ncores, "all" if quota is None else ("%g" % quota)),
             "single_thread_qps": qps1, "single_thread_us_per_query": 1e6 / qps1,
             "single_thread_passes_us_per_query": [x * 1e6 / ns for x in singles],
             "host_cores": ncores, "cpu_quota_cpus": quota, "thread_sweep_qps": {str(k_): v_ for k_, v_ in sorted(sweep.items())},

@@ -35,7 +35,7 @@ namespace sgpu {
   } while (0)
 
 constexpr int kAssignThreads = 256;            // 4 wavefronts per workgroup, a document each
-constexpr uint32_t kAssignMaxCentroids = 4096;  // accumulators of a wavefront: 16 KB of LDS
+constexpr uint32_t kAssignMaxCentroids = 8192;  // accumulators of a wavefront: up to 32 KB of LDS (r04: 8192; lists of n_postings 6000 x max_fraction 4 x centroid_fraction 0.2 = 4800 centroids stayed on the host, 25 s)
 
 struct AssignView {
   // documents (the forward index as the builder holds it)

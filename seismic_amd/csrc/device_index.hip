@@ -701,6 +701,12 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
     sgpu_batch_plan& pl = *out;
     pl.query_cut = query_cut;
     std::vector<std::pair<uint64_t, uint32_t>> cost(nq);
+    // (experiment, SGPU_AFFINITY_CLASSES = n > 0: inside each of n cost classes of the longest-first order, queries
+    // that walk the same first list are queued next to each other - they then run at the same time on different
+    // workgroups and meet each other's summary rows and records in the Infinity Cache)
+    const uint32_t aff_classes = nq >= 4096 ? env_u32("SGPU_AFFINITY_CLASSES", 0) : 0;
+    std::vector<uint32_t> first_list;
+    if (aff_classes) first_list.resize(nq);
     uint32_t max_nb = 0, dots_cap = 1, max_list_nb = 1;
     {   // serial on purpose (about a millisecond per 10 000 queries; an OpenMP team costs more to wake)
       std::vector<std::pair<int32_t, uint32_t>> kv;
@@ -723,6 +729,7 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
         if (nl) max_nb = std::max(max_nb, d->list_nb[kv[0].second]);
         dots_cap = std::max(dots_cap, nb);
         cost[(size_t)q] = {np, (uint32_t)q};
+        if (!first_list.empty()) first_list[(size_t)q] = nl ? kv[0].second : 0xffffffffu;
       }
     }
     pl.max_nb = max_nb;
@@ -730,6 +737,14 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
     pl.max_list_nb = max_list_nb;
     std::stable_sort(cost.begin(), cost.end(),
                      [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) { return a.first > c.first; });
+    if (aff_classes) {
+      const size_t per = ((size_t)nq + aff_classes - 1) / aff_classes;
+      for (size_t c0 = 0; c0 < nq; c0 += per)
+        std::stable_sort(cost.begin() + (long)c0, cost.begin() + (long)std::min<size_t>(nq, c0 + per),
+                         [&](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) {
+                           return first_list[a.second] < first_list[c.second];
+                         });
+    }
     pl.order.resize(2 * (size_t)nq);
     for (uint32_t i = 0; i < nq; ++i) pl.order[i] = cost[i].second;
     // LK_HASH seeds: the first multiplier of the family that sends the query's components to distinct slots
