@@ -73,8 +73,9 @@ def parse_args():
     ap.add_argument("--max-fraction", type=float, default=6.0)
     ap.add_argument("--min-cluster-size", type=int, default=2)
     ap.add_argument("--comp-width", type=int, default=2, choices=[2, 4])
-    ap.add_argument("--value-type", default="f16", choices=["f16", "fixedu8"],
-                    help="document value storage (fixedu8: the forward index of the reference's DotVByte index)")
+    ap.add_argument("--value-type", default="f16", choices=["f16", "fixedu8", "dotvbyte"],
+                    help="forward index storage (fixedu8: u8 fixed-point values; dotvbyte: those plus the compressed "
+                         "component stream - the forward index of the reference's DotVByte index)")
     ap.add_argument("--sample", type=int, default=1000,
                     help="queries of the first timed batch used for recall, the oracle identity check and cpu_baseline")
     ap.add_argument("--build-on-host", action="store_true",
@@ -309,8 +310,8 @@ def main():
             allq = _native.read_inner_format(qpath)
         else:
             index, allq, _, _, _ = prepare(False)
-    if args.value_type == "fixedu8":   # convert_dataset_into: same lists / blocks / summaries, u8 forward values
-        index = index.convert(1)
+    if args.value_type != "f16":   # convert_dataset_into: same lists / blocks / summaries, the forward index re-encoded
+        index = index.convert(1 if args.value_type == "fixedu8" else 2)
     t0 = time.time()
     index.upload(local_rank)
     t_up = time.time() - t0
@@ -389,6 +390,9 @@ def main():
     # every timed batch gets one extra pass with the visited set materialised (sgpu_batch_run_counted):
     # identical results, and work counters that exclude re-encountered documents exactly as the
     # reference does -> algorithmic bytes of each launch
+    # bytes per document element as stored: f16 2 + 2, fixed-u8 2 + 1, DotVByte 1.5 (eight 12-bit gaps per slice) + 1
+    val_bytes = 2 if args.value_type == "f16" else 1
+    doc_comp_bytes = 1.5 if args.value_type == "dotvbyte" else None
     algo, counted_identical, results = [], True, {}
     entry_identical = True
     agg = np.zeros(8, np.float64)
@@ -407,7 +411,7 @@ def main():
         csc, cid, cn = b.fetch(args.k)
         counted_identical &= bool(np.array_equal(cn, gn) and np.array_equal(cid, gid)
                                   and np.array_equal(csc.view(np.uint32), gsc.view(np.uint32)))
-        ab, counters = b.algorithmic_bytes(args.k, args.comp_width, 2 if args.value_type == "f16" else 1)
+        ab, counters = b.algorithmic_bytes(args.k, args.comp_width, val_bytes, doc_comp_bytes)
         algo.append(ab)
         agg += counters[:, :8].sum(axis=0)
         results[bi] = (gsc, gid, gn)
@@ -453,7 +457,9 @@ def main():
                       "n_postings_kept": int(d.n_postings), "summary_entries": int(d.n_entries)},
             "query": {"k": args.k, "query_cut": args.query_cut, "heap_factor": args.heap_factor,
                       "first_sorted": srt},
-            "storage": "%s document values, u%d components, u8-quantised block summaries" % (args.value_type, 8 * args.comp_width),
+            "storage": "%s, u8-quantised block summaries" % (
+                "fixed-u8 document values, 12-bit component gaps (DotVByte forward index, 2.5 B per element)" if args.value_type == "dotvbyte"
+                else "%s document values, u%d components" % (args.value_type, 8 * args.comp_width)),
             "parallelism": "index replicated, %s, no collective" % (
                 ("each batch of %d cut into %d contiguous shards" % (args.queries, world)) if scaling == "strong" and world > 1
                 else ("%d batch(es) of %d per step" % (world, args.queries))),
@@ -664,8 +670,8 @@ def main():
             ix_ = _native.NativeIndex.build(args.comp_width, int(d.dim), *docs_, cfg_)
             del docs_
             tb_ = time.time() - t1
-            if args.value_type == "fixedu8":
-                ix_ = ix_.convert(1)
+            if args.value_type != "f16":
+                ix_ = ix_.convert(1 if args.value_type == "fixedu8" else 2)
             t1 = time.time()
             ix_.upload(local_rank)
             tu_ = time.time() - t1
@@ -724,7 +730,7 @@ def main():
                 b_.run(args.k, cut, hf, fs, sync=False)
             st_ = bs_[0].sync()
             bs_[0].run_counted(args.k, cut, hf, fs)
-            ab, cst = bs_[0].algorithmic_bytes(args.k, args.comp_width, 2 if args.value_type == "f16" else 1)
+            ab, cst = bs_[0].algorithmic_bytes(args.k, args.comp_width, val_bytes, doc_comp_bytes)
             psc, pid, pn = bs_[0].fetch(args.k)
             dx = ix_.desc
             osc, oid, on_, _, secs_1, _ = orc.batch_search(dx, s_off, s_comp, s_val, args.k, cut, hf, fs, num_threads=1, tuned=True)

@@ -78,12 +78,22 @@ typedef enum sgpu_status {
  *                    two with 255 * val_scale >= the largest value (2^-8, i.e. Q0.8, for values
  *                    below 1); code = min(255, round_half_away(v / val_scale)), negatives -> 0.
  *                    Either component width (the reference's "fixedu8" goes with u16 and u32 components,
- *                    src/bin/perf_inverted_index.rs:110-126; its DotVByte class is u16-only). */
-enum { SGPU_VAL_F16 = 0, SGPU_VAL_FIXEDU8 = 1 };
+ *                    src/bin/perf_inverted_index.rs:110-126; its DotVByte class is u16-only).
+ *   SGPU_VAL_DOTVBYTE the forward index of the reference's DotVByte index (SeismicIndexDotVByte,
+ *                    src/pylib/dotvbyte.rs:15-22, 208-213; `dotvbyte` value type of the CLI,
+ *                    src/bin/perf_inverted_index.rs:110-126): the FIXEDU8 values PLUS a compressed
+ *                    component stream. The host-side arrays of the descriptor are those of FIXEDU8 (u16
+ *                    components, u8 codes); the compression is the HBM layout: eight 12-bit component gaps
+ *                    per 8-element slice (three dwords instead of four), a document with a first component or
+ *                    a gap >= 4096 keeps the raw record form. The reference's codec (vectorium's DotVByte, a
+ *                    variable-byte gap stream) is not in the tree: PARITY UNPINNED; it is lossless, so results
+ *                    are those of the FIXEDU8 index - which is what the tests assert. u16 components only (as the
+ *                    reference's class), documents of fewer than 32768 components. */
+enum { SGPU_VAL_F16 = 0, SGPU_VAL_FIXEDU8 = 1, SGPU_VAL_DOTVBYTE = 2 };
 
 typedef struct sgpu_index_desc {
   uint32_t comp_width;            /* 2 (SeismicIndex, u16) or 4 (SeismicIndexLV, u32) */
-  uint32_t value_type;            /* SGPU_VAL_F16 or SGPU_VAL_FIXEDU8: how fwd_vals stores document values */
+  uint32_t value_type;            /* SGPU_VAL_F16, SGPU_VAL_FIXEDU8 or SGPU_VAL_DOTVBYTE: how fwd_vals stores document values */
   uint64_t n_docs;
   uint64_t dim;                   /* number of components == number of posting lists */
   uint64_t nnz;                   /* fwd_offsets[n_docs] */
@@ -93,7 +103,7 @@ typedef struct sgpu_index_desc {
   uint64_t n_entries;             /* row_ptr[n_rows] */
   const uint64_t* fwd_offsets;    /* n_docs + 1 */
   const void* fwd_comps;          /* nnz x comp_width bytes */
-  const void* fwd_vals;           /* nnz binary16 bit patterns (F16) or nnz u8 codes (FIXEDU8) */
+  const void* fwd_vals;           /* nnz binary16 bit patterns (F16) or nnz u8 codes (FIXEDU8, DOTVBYTE) */
   const uint64_t* list_block_start; /* dim + 1 */
   const uint64_t* block_post_start; /* n_blocks + 1 */
   const uint32_t* post_doc;       /* n_postings */
@@ -104,7 +114,7 @@ typedef struct sgpu_index_desc {
   const uint64_t* row_ptr;        /* n_rows + 1 */
   const uint16_t* sum_bid;        /* n_entries */
   const uint8_t* sum_code;        /* n_entries */
-  float val_scale;                /* FIXEDU8: value = code * val_scale (a power of two); 0 for F16 */
+  float val_scale;                /* FIXEDU8 / DOTVBYTE: value = code * val_scale (a power of two); 0 for F16 */
   uint32_t reserved;
 } sgpu_index_desc;
 

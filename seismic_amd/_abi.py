@@ -3,7 +3,7 @@ import ctypes as C
 
 SGPU_OK, SGPU_EINVAL, SGPU_EDEVICE, SGPU_ENOMEM, SGPU_EIO, SGPU_ELIMIT = range(6)
 ABI_VERSION = 4
-SGPU_VAL_F16, SGPU_VAL_FIXEDU8 = 0, 1
+SGPU_VAL_F16, SGPU_VAL_FIXEDU8, SGPU_VAL_DOTVBYTE = 0, 1, 2
 
 u8p = C.POINTER(C.c_uint8)
 u16p = C.POINTER(C.c_uint16)

@@ -149,7 +149,8 @@ class NativeIndex:
 
     def convert(self, value_type):
         """InvertedIndexBase::convert_dataset_into: a new index whose forward index stores the document
-        values as `value_type` (0 = f16, 1 = fixed-u8); lists, blocks and summaries are shared."""
+        values as `value_type` (0 = f16, 1 = fixed-u8, 2 = DotVByte: fixed-u8 + compressed component stream);
+        lists, blocks and summaries are shared."""
         h = C.c_void_p()
         check(lib().sgpu_index_convert(self.h, int(value_type), C.byref(h)))
         return NativeIndex(h.value)
@@ -309,13 +310,15 @@ class DeviceBatch:
         check(lib().sgpu_batch_fetch_stats(self.index.h, self.h, _p(st)))
         return st[: self.nq]
 
-    def algorithmic_bytes(self, k, comp_width, val_bytes=2):
+    def algorithmic_bytes(self, k, comp_width, val_bytes=2, doc_comp_bytes=None):
         """B_q of SURVEY.md 8(d), summed over the batch, from the kernel's own work counters
-        (val_bytes: 2 for f16 document values, 1 for fixed-u8)."""
+        (val_bytes: 2 for f16 document values, 1 for fixed-u8; doc_comp_bytes: bytes per document component as
+        stored, comp_width unless the component stream is compressed - 1.5 for DotVByte's 12-bit gaps)."""
         st = self.fetch_stats().astype(np.int64)
         nnz_q = np.diff(self.q_off.astype(np.int64))
+        per_elem = (comp_width if doc_comp_bytes is None else doc_comp_bytes) + val_bytes
         b = (nnz_q * (comp_width + 4) + 12 * k + 8 * st[:, 0] + 8 * st[:, 1] + 3 * st[:, 2]
-             + 4 * (st[:, 4] + st[:, 3]) + 8 * st[:, 5] + st[:, 6] * (comp_width + val_bytes))
+             + 4 * (st[:, 4] + st[:, 3]) + 8 * st[:, 5] + st[:, 6] * per_elem)
         return int(b.sum()), st
 
     def close(self):

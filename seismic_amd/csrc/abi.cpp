@@ -517,6 +517,33 @@ uint32_t sgpu_debug_chunk_plan(uint32_t nq, uint32_t chunk_min, uint32_t chunk_m
   return n_jobs;
 }
 
+// (not part of the boundary: the forward store as sgpu_index_upload packs it - document-major records - and the ref
+// of every document, (record offset / 16) << 16 | length field; out_fwd == null: *out_bytes = the size needed.
+// tests/test_abi_and_host.py decodes every record with the oracle's restatement of the layout.)
+sgpu_status sgpu_debug_pack_forward(const sgpu_index* idx, uint8_t* out_fwd, uint64_t cap, uint64_t* out_doc_ref, uint64_t* out_bytes) {
+  if (!idx || !out_bytes) return fail(SGPU_EINVAL, "null argument");
+  try {
+    std::vector<uint8_t> raw, fwd;
+    std::vector<uint64_t> off16, dref;
+    pack_dvb_raw_flags(idx->host, &raw);
+    pack_record_offsets(idx->host, raw, 128 / 16, &off16);
+    *out_bytes = std::max<uint64_t>(off16[idx->host.n_docs] * 16, 16);
+    if (!out_fwd) return SGPU_OK;
+    if (cap < *out_bytes || !out_doc_ref) return fail(SGPU_EINVAL, "buffer too small");
+    pack_records(idx->host, raw, off16, &fwd);
+    pack_doc_refs(idx->host, raw, off16, &dref);
+    std::memcpy(out_fwd, fwd.data(), fwd.size());
+    std::memcpy(out_doc_ref, dref.data(), dref.size() * 8);
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of host memory");
+  }
+  return SGPU_OK;
+}
+
+// (not part of the boundary: the calling thread's staged calls add the wall time of their host-side phases to
+// buf[0..7] from now on - see device_index.hip: call_timing; null switches it off. tools/shard_probe.py)
+void sgpu_debug_call_timing(double* buf8) { call_timing() = buf8; }
+
 // (not part of the boundary: the timeline of a cooperative launch, for tools/coop_trace.py on a trace build)
 uint32_t sgpu_debug_coop_trace(sgpu_index* idx, uint64_t* out, uint32_t cap) {
   return idx ? coop_trace_dump(idx->dev, out, cap) : 0;

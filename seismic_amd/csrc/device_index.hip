@@ -28,8 +28,13 @@ hipError_t run_u32_packed_u8(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_hash(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_hash_u8(const LaunchArgs& a, int* occupancy);
 hipError_t run_u32_split_u8(const LaunchArgs& a, int* occupancy);
+hipError_t run_u16_dense_dvb(const LaunchArgs& a, int* occupancy);
+hipError_t run_u16_packed_dvb(const LaunchArgs& a, int* occupancy);
+hipError_t run_u16_hash_dvb(const LaunchArgs& a, int* occupancy);
 
 static hipError_t run_any(const LaunchArgs& a, int* occ) {
+  if (a.value_type == SGPU_VAL_DOTVBYTE)   // (u16 components only)
+    return a.lookup == LK_HASH ? run_u16_hash_dvb(a, occ) : (a.lookup == LK_DENSE ? run_u16_dense_dvb(a, occ) : run_u16_packed_dvb(a, occ));
   if (a.value_type == SGPU_VAL_FIXEDU8 && a.comp_width == 4) return a.lookup == LK_SPLIT ? run_u32_split_u8(a, occ) : run_u32_packed_u8(a, occ);
   if (a.value_type == SGPU_VAL_FIXEDU8)
     return a.lookup == LK_HASH ? run_u16_hash_u8(a, occ) : (a.lookup == LK_DENSE ? run_u16_dense_u8(a, occ) : run_u16_packed_u8(a, occ));
@@ -212,14 +217,20 @@ int device_count() {
 __global__ __launch_bounds__(256) void replicate_records_kernel(uint8_t* fwd, const uint64_t* __restrict__ doc_ref,
                                                                 const uint32_t* __restrict__ post_doc,
                                                                 const uint64_t* __restrict__ post_ref, uint64_t n_postings,
-                                                                uint32_t bytes_per_elem) {
+                                                                uint32_t bytes_per_elem, uint32_t dvb) {
   const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const uint32_t sub = threadIdx.x & 15;
   const uint64_t n_groups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
   for (uint64_t p = g; p < n_postings; p += n_groups) {
     const uint64_t dst = post_ref[p], src = doc_ref[post_doc[p]];
-    const uint32_t len = (uint32_t)(dst & 0xffffu);
-    const uint32_t n16 = (((len + 7u) & ~7u) * bytes_per_elem + 15u) >> 4;   // 16-byte units of the record
+    uint32_t n16;   // 16-byte units of the record
+    if (dvb && !(dst & 0x8000u)) {   // DotVByte: [ns x 12 B gaps][pad to 8][ns x 8 B codes]
+      const uint32_t ns = (((uint32_t)dst & 0x7fffu) + 7u) >> 3;
+      n16 = ((((ns * 12u + 7u) & ~7u) + ns * 8u) + 15u) >> 4;
+    } else {
+      const uint32_t len = (uint32_t)dst & (dvb ? 0x7fffu : 0xffffu);
+      n16 = (((len + 7u) & ~7u) * bytes_per_elem + 15u) >> 4;
+    }
     const uint4* s4 = (const uint4*)(fwd + (src >> 16) * 16ull);
     uint4* d4 = (uint4*)(fwd + (dst >> 16) * 16ull);
     for (uint32_t i = sub; i < n16; i += 16) d4[i] = s4[i];
@@ -260,13 +271,15 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     // otherwise touch more lines than its size needs: at 16-byte alignment a 480-byte record straddles
     // ~4.75 lines, line-fitted 4.
     std::vector<uint64_t> rec_off16;
+    std::vector<uint8_t> dvb_raw;   // DotVByte: the documents that keep the raw record form (a gap >= 4096)
+    pack_dvb_raw_flags(h, &dvb_raw);
     {
       const char* env_line = std::getenv("SGPU_REC_LINE");
-      pack_record_offsets(h, std::max<uint64_t>(16, env_line ? std::strtoul(env_line, nullptr, 10) : 128) / 16, &rec_off16);
+      pack_record_offsets(h, dvb_raw, std::max<uint64_t>(16, env_line ? std::strtoul(env_line, nullptr, 10) : 128) / 16, &rec_off16);
     }
     if (rec_off16[h.n_docs] >= (1ull << 48)) return bail(fail(SGPU_ELIMIT, "forward index exceeds 48-bit record offsets"));
     std::vector<uint8_t> fwd;
-    pack_records(h, rec_off16, &fwd);
+    pack_records(h, dvb_raw, rec_off16, &fwd);
     // ---- postings: (record offset / 16) << 16 | len, the reference's PackedPostingBlock
     // (src/posting_list.rs:32-60). Forward store layout:
     //   block-major (default when it fits): after the document-major records, every posting gets its
@@ -283,7 +296,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     uint64_t blk_units = 0;
     {
       std::vector<uint64_t> bsize;
-      pack_block_sizes(h, &bsize);
+      pack_block_sizes(h, dvb_raw, &bsize);
       blk_units = bsize[h.n_blocks()];
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
@@ -300,14 +313,14 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       size_t fbytes = 0;
       for (;;) {
         const uint64_t total_units = block_major ? blk_base + blk_units : doc_units;
-        fbytes = std::max<uint64_t>(total_units * 16, 16);
+        fbytes = std::max<uint64_t>(total_units * 16, 16) + 16;   // (+16: a 16-byte load may start 12 bytes before the end)
         if (hipMalloc(&fp, fbytes) == hipSuccess) break;
         (void)hipGetLastError();
         if (!block_major) return bail(fail(SGPU_ENOMEM, "hipMalloc of %zu bytes failed", fbytes));
         block_major = false;
       }
       d->fwd_block_major = block_major;
-      pack_post_refs(h, rec_off16, bsize, block_major, blk_base, &pref);
+      pack_post_refs(h, dvb_raw, rec_off16, bsize, block_major, blk_base, &pref);
       d->allocs.push_back(Alloc{fp, fbytes, (size_t)((const char*)&d->view.fwd - (const char*)d)});
       d->bytes += fbytes;
       d->view.fwd = (const uint8_t*)fp;
@@ -319,7 +332,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     if ((st = dev_copy(d, pref.data(), pref.size(), &d->view.post_ref)) != SGPU_OK) return bail(st);
     {
       std::vector<uint64_t> dref;
-      pack_doc_refs(h, rec_off16, &dref);
+      pack_doc_refs(h, dvb_raw, rec_off16, &dref);
       if ((st = dev_copy(d, dref.data(), dref.size(), &d->view.doc_ref)) != SGPU_OK) return bail(st);
     }
     pref.clear();
@@ -328,7 +341,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     if (d->fwd_block_major && h.n_postings()) {
       hipLaunchKernelGGL(replicate_records_kernel, dim3(d->n_cu * 8), dim3(256), 0, d->main.stream,
                          (uint8_t*)d->view.fwd, d->view.doc_ref, d->view.post_doc, d->view.post_ref,
-                         (uint64_t)h.n_postings(), (uint32_t)(cw + vb));
+                         (uint64_t)h.n_postings(), (uint32_t)(cw + vb), (uint32_t)(h.value_type == SGPU_VAL_DOTVBYTE));
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(d->main.stream));
     }
@@ -701,50 +714,65 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
     sgpu_batch_plan& pl = *out;
     pl.query_cut = query_cut;
     std::vector<std::pair<uint64_t, uint32_t>> cost(nq);
-    // (experiment, SGPU_AFFINITY_CLASSES = n > 0: inside each of n cost classes of the longest-first order, queries
-    // that walk the same first list are queued next to each other - they then run at the same time on different
-    // workgroups and meet each other's summary rows and records in the Infinity Cache)
-    const uint32_t aff_classes = nq >= 4096 ? env_u32("SGPU_AFFINITY_CLASSES", 0) : 0;
-    std::vector<uint32_t> first_list;
-    if (aff_classes) first_list.resize(nq);
     uint32_t max_nb = 0, dots_cap = 1, max_list_nb = 1;
-    {   // serial on purpose (about a millisecond per 10 000 queries; an OpenMP team costs more to wake)
-      std::vector<std::pair<int32_t, uint32_t>> kv;
+    {   // serial on purpose (an OpenMP team costs more to wake than this takes): ~60 ns per query for query_cut <= 16
+      constexpr uint32_t kSmall = 16;
+      std::vector<std::pair<int32_t, uint32_t>> kv;   // (large query_cut only)
       for (int64_t q = 0; q < (int64_t)nq; ++q) {
-        kv.clear();
-        for (uint64_t i = h_off[q]; i < h_off[q + 1]; ++i) kv.emplace_back(total_key(h_val[i]), h_comp[i]);
-        const size_t nl = std::min<size_t>(query_cut, kv.size());
-        std::partial_sort(kv.begin(), kv.begin() + (long)nl, kv.end(),
-                          [](const std::pair<int32_t, uint32_t>& a, const std::pair<int32_t, uint32_t>& c) {
-                            if (a.first != c.first) return a.first > c.first;
-                            return a.second < c.second;
-                          });
+        const uint64_t qa = h_off[q], qe = h_off[q + 1];
+        // the query_cut heaviest components by (f32::total_cmp descending, component ascending) - the order the
+        // kernel's select_lists produces. Components arrive ascending, so of two equal keys the earlier one wins.
+        int32_t tk[kSmall];
+        uint32_t tc[kSmall];
+        const uint32_t* sel = tc;
+        size_t nl = 0;
+        if (query_cut <= kSmall) {
+          for (uint64_t i = qa; i < qe; ++i) {
+            const int32_t key = total_key(h_val[i]);
+            if (nl == query_cut && !(key > tk[nl - 1])) continue;
+            size_t j = nl < query_cut ? nl++ : nl - 1;
+            while (j > 0 && tk[j - 1] < key) {
+              tk[j] = tk[j - 1];
+              tc[j] = tc[j - 1];
+              --j;
+            }
+            tk[j] = key;
+            tc[j] = h_comp[i];
+          }
+        } else {
+          kv.clear();
+          for (uint64_t i = qa; i < qe; ++i) kv.emplace_back(total_key(h_val[i]), h_comp[i]);
+          nl = std::min<size_t>(query_cut, kv.size());
+          std::partial_sort(kv.begin(), kv.begin() + (long)nl, kv.end(),
+                            [](const std::pair<int32_t, uint32_t>& a, const std::pair<int32_t, uint32_t>& c) {
+                              if (a.first != c.first) return a.first > c.first;
+                              return a.second < c.second;
+                            });
+        }
         uint64_t np = 0;
         uint32_t nb = 0;
         for (size_t i = 0; i < nl; ++i) {
-          nb += d->list_nb[kv[i].second];
-          np += d->list_np[kv[i].second];
-          max_list_nb = std::max(max_list_nb, d->list_nb[kv[i].second]);
+          const uint32_t c = query_cut <= kSmall ? sel[i] : kv[i].second;
+          nb += d->list_nb[c];
+          np += d->list_np[c];
+          max_list_nb = std::max(max_list_nb, d->list_nb[c]);
         }
-        if (nl) max_nb = std::max(max_nb, d->list_nb[kv[0].second]);
+        const uint32_t c0 = nl ? (query_cut <= kSmall ? sel[0] : kv[0].second) : 0xffffffffu;
+        if (nl) max_nb = std::max(max_nb, d->list_nb[c0]);
         dots_cap = std::max(dots_cap, nb);
         cost[(size_t)q] = {np, (uint32_t)q};
-        if (!first_list.empty()) first_list[(size_t)q] = nl ? kv[0].second : 0xffffffffu;
       }
     }
     pl.max_nb = max_nb;
     pl.dots_cap = dots_cap;
     pl.max_list_nb = max_list_nb;
-    std::stable_sort(cost.begin(), cost.end(),
-                     [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) { return a.first > c.first; });
-    if (aff_classes) {
-      const size_t per = ((size_t)nq + aff_classes - 1) / aff_classes;
-      for (size_t c0 = 0; c0 < nq; c0 += per)
-        std::stable_sort(cost.begin() + (long)c0, cost.begin() + (long)std::min<size_t>(nq, c0 + per),
-                         [&](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) {
-                           return first_list[a.second] < first_list[c.second];
-                         });
-    }
+    // longest expected first, ties in input order (cost descending, query ascending: a total order, so a plain sort)
+    std::sort(cost.begin(), cost.end(), [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) {
+      return a.first != c.first ? a.first > c.first : a.second < c.second;
+    });
+    // (measured r04 and dropped: queueing queries that walk the same first list next to each other inside 16 / 64 /
+    // 256 cost classes, so that they meet each other's lines in the Infinity Cache: 5.94 ms per 10 000-query launch
+    // without, 5.95 / 5.98 / 5.91 with - noise)
     pl.order.resize(2 * (size_t)nq);
     for (uint32_t i = 0; i < nq; ++i) pl.order[i] = cost[i].second;
     // LK_HASH seeds: the first multiplier of the family that sends the query's components to distinct slots
@@ -842,7 +870,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   L.q_comp = (uint32_t)o; o += up((uint64_t)qn * 4);
   L.q_val = (uint32_t)o; o += up(((uint64_t)qn + 1) * 4);   // + the 0.0 slot non-matching components resolve to
   L.q_sc = L.q_val;   // fixed-u8 documents: a second copy of the weights, scaled by val_scale
-  if (d->value_type == SGPU_VAL_FIXEDU8) {
+  if (d->value_type != SGPU_VAL_F16) {
     L.q_sc = (uint32_t)o;
     o += up(((uint64_t)qn + 1) * 4);
   }
@@ -903,7 +931,9 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
                         !env_u32("SGPU_NO_DENSE", 0) && searching;
   const uint64_t split_bits = up((uint64_t)words * 4), split_bytes = split_bits + up((uint64_t)words * 2);
   // the round's item tables shrink (down to 256 items) if that is what keeps 2 workgroups per CU
-  auto uni_for = [&](uint32_t items) { return up(std::max<uint64_t>((uint64_t)items * 16 + NT * 12, sort_bytes)); };
+  // (a DotVByte index: + the round's list of raw-form items, ChunkBufs::it_raw)
+  const uint64_t raw_list = d->value_type == SGPU_VAL_DOTVBYTE ? 2u : 0u;
+  auto uni_for = [&](uint32_t items) { return up(std::max<uint64_t>((uint64_t)items * (16 + raw_list) + NT * 12, sort_bytes)); };
   const uint64_t smallest_lookup = (d->comp_width == 4) ? split_bytes : bitmap_bytes;
   const uint32_t want_items = items_max;
   if (!env_get("SGPU_ITEMS_MAX")) {

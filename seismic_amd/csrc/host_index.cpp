@@ -103,8 +103,10 @@ static bool monotone(const uint64_t* a, uint64_t n_plus_1, uint64_t last) {
 sgpu_status validate_desc(const sgpu_index_desc& d) {
   if (d.comp_width != 2 && d.comp_width != 4) return fail(SGPU_EINVAL, "comp_width must be 2 or 4");
   if (d.dim == 0) return fail(SGPU_EINVAL, "dim == 0");
-  if (d.value_type != SGPU_VAL_F16 && d.value_type != SGPU_VAL_FIXEDU8) return fail(SGPU_EINVAL, "unknown value_type %u", d.value_type);
-  if (d.value_type == SGPU_VAL_FIXEDU8) {
+  if (d.value_type > SGPU_VAL_DOTVBYTE) return fail(SGPU_EINVAL, "unknown value_type %u", d.value_type);
+  if (d.value_type == SGPU_VAL_DOTVBYTE && d.comp_width != 2)
+    return fail(SGPU_EINVAL, "a DotVByte index has u16 components (reference src/pylib/dotvbyte.rs:20-27)");
+  if (d.value_type != SGPU_VAL_F16) {
     int e = 0;
     if (!(d.val_scale > 0.0f) || std::frexp(d.val_scale, &e) != 0.5f) return fail(SGPU_EINVAL, "val_scale must be a positive power of two");
   }
@@ -127,6 +129,7 @@ sgpu_status validate_desc(const sgpu_index_desc& d) {
   for (uint64_t doc = 0; doc < d.n_docs; ++doc) {
     const uint64_t s = d.fwd_offsets[doc], e = d.fwd_offsets[doc + 1];
     if (e - s > 65535) return fail(SGPU_EINVAL, "document %llu has more than 65535 components (16-bit length, reference src/posting_list.rs:45-48)", (unsigned long long)doc);
+    if (d.value_type == SGPU_VAL_DOTVBYTE && e - s > 32767) return fail(SGPU_EINVAL, "document %llu has more than 32767 components (DotVByte forward index)", (unsigned long long)doc);
     for (uint64_t i = s; i < e; ++i) {
       const uint32_t c = compv(d.fwd_comps, i);
       if (c >= d.dim) return fail(SGPU_EINVAL, "document component >= dim");
@@ -296,7 +299,8 @@ sgpu_status host_index_load(const char* path, HostIndex* out) {
     const uint32_t scale_bits = (uint32_t)hdr[11];
     std::memcpy(&h.val_scale, &scale_bits, 4);
   }
-  bool ok = (h.comp_width == 2 || h.comp_width == 4) && (h.value_type == SGPU_VAL_F16 || h.value_type == SGPU_VAL_FIXEDU8);
+  bool ok = (h.comp_width == 2 || h.comp_width == 4) && h.value_type <= SGPU_VAL_DOTVBYTE &&
+            (h.value_type != SGPU_VAL_DOTVBYTE || h.comp_width == 2);
   const uint64_t vb = h.value_type == SGPU_VAL_F16 ? 2 : 1;
   // the header is untrusted: the counts must add up to the file's size before anything is resized
   if (ok) {
@@ -344,15 +348,26 @@ sgpu_status host_index_load(const char* path, HostIndex* out) {
 
 // InvertedIndexBase::convert_dataset_into: same lists / blocks / summaries, the forward index re-encoded.
 sgpu_status host_index_convert(const HostIndex& src, uint32_t value_type, HostIndex* out) {
-  if (value_type != SGPU_VAL_F16 && value_type != SGPU_VAL_FIXEDU8) return fail(SGPU_EINVAL, "unknown value_type %u", value_type);
-  // (either component width: the reference's "fixedu8" value type goes with u16 and with u32 components,
-  // src/bin/perf_inverted_index.rs:110-126; only its DotVByte class is u16-only, src/pylib/dotvbyte.rs:20-27)
+  if (value_type > SGPU_VAL_DOTVBYTE) return fail(SGPU_EINVAL, "unknown value_type %u", value_type);
+  // (either component width for fixed-u8: the reference's "fixedu8" value type goes with u16 and with u32 components,
+  // src/bin/perf_inverted_index.rs:110-126; its DotVByte class is u16-only, src/pylib/dotvbyte.rs:20-27)
+  if (value_type == SGPU_VAL_DOTVBYTE) {
+    if (src.comp_width != 2) return fail(SGPU_EINVAL, "a DotVByte index has u16 components (reference src/pylib/dotvbyte.rs:20-27)");
+    for (uint64_t doc = 0; doc < src.n_docs; ++doc)
+      if (src.fwd_offsets[doc + 1] - src.fwd_offsets[doc] > 32767)
+        return fail(SGPU_ELIMIT, "document %llu has more than 32767 components (DotVByte forward index)", (unsigned long long)doc);
+  }
   try {
     *out = src;
     HostIndex& h = *out;
     const uint64_t nnz = src.nnz();
     if (value_type == src.value_type) return SGPU_OK;
-    if (value_type == SGPU_VAL_FIXEDU8) {
+    // DotVByte <-> fixed-u8: the same codes, the component stream is (de)compressed at upload
+    if (value_type != SGPU_VAL_F16 && src.value_type != SGPU_VAL_F16) {
+      h.value_type = value_type;
+      return SGPU_OK;
+    }
+    if (value_type != SGPU_VAL_F16) {
       // [restated, parity unpinned] step = smallest power of two with 255 * step >= max value
       float vmax = 0.0f;
       for (uint64_t i = 0; i < nnz; ++i) {
@@ -361,7 +376,7 @@ sgpu_status host_index_convert(const HostIndex& src, uint32_t value_type, HostIn
       }
       float step = 0.00390625f;   // 2^-8: Q0.8
       while (255.0f * step < vmax) step *= 2.0f;
-      h.value_type = SGPU_VAL_FIXEDU8;
+      h.value_type = value_type;
       h.val_scale = step;
       h.fwd_codes.resize(nnz);
       h.fwd_vals.clear();

@@ -44,7 +44,7 @@ struct HostIndex {
   inline float val(uint64_t i) const {   // document value i as f32 (exact for both value types)
     return value_type == SGPU_VAL_F16 ? f16_to_f32(fwd_vals[i]) : (float)fwd_codes[i] * val_scale;
   }
-  inline uint32_t val_bytes() const { return value_type == SGPU_VAL_F16 ? 2u : 1u; }
+  inline uint32_t val_bytes() const { return value_type == SGPU_VAL_F16 ? 2u : 1u; }   // (fixed-u8 and DotVByte: u8 codes)
   inline uint32_t rcomp(uint64_t i) const {
     return comp_width == 2 ? (uint32_t)((const uint16_t*)row_comp.data())[i]
                            : ((const uint32_t*)row_comp.data())[i];
@@ -67,12 +67,14 @@ sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t
 // the offsets alone (monotone, query and batch size limits): what has to hold before a batch is cut
 sgpu_status validate_query_offsets(const uint64_t* q_off, uint32_t nq, uint32_t q_base, uint32_t* max_nnz);
 // pack_index.cpp: the host half of the upload (HBM layout of DESIGN.md section 2), on all host cores
-void pack_record_offsets(const HostIndex& h, uint64_t line16, std::vector<uint64_t>* rec_off16);
-void pack_records(const HostIndex& h, const std::vector<uint64_t>& rec_off16, std::vector<uint8_t>* fwd);
-void pack_block_sizes(const HostIndex& h, std::vector<uint64_t>* bsize);
-void pack_post_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, const std::vector<uint64_t>& bsize,
-                    bool block_major, uint64_t blk_base, std::vector<uint64_t>* pref);
-void pack_doc_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, std::vector<uint64_t>* dref);
+// (raw: per document, 1 = a DotVByte index keeps the document in the raw record form; empty for the other value types)
+void pack_dvb_raw_flags(const HostIndex& h, std::vector<uint8_t>* raw);
+void pack_record_offsets(const HostIndex& h, const std::vector<uint8_t>& raw, uint64_t line16, std::vector<uint64_t>* rec_off16);
+void pack_records(const HostIndex& h, const std::vector<uint8_t>& raw, const std::vector<uint64_t>& rec_off16, std::vector<uint8_t>* fwd);
+void pack_block_sizes(const HostIndex& h, const std::vector<uint8_t>& raw, std::vector<uint64_t>* bsize);
+void pack_post_refs(const HostIndex& h, const std::vector<uint8_t>& raw, const std::vector<uint64_t>& rec_off16,
+                    const std::vector<uint64_t>& bsize, bool block_major, uint64_t blk_base, std::vector<uint64_t>* pref);
+void pack_doc_refs(const HostIndex& h, const std::vector<uint8_t>& raw, const std::vector<uint64_t>& rec_off16, std::vector<uint64_t>* dref);
 void pack_narrow(const std::vector<uint64_t>& v, std::vector<uint32_t>* out);
 void pack_row_mid(const HostIndex& h, std::vector<uint16_t>* mid);
 void pack_sum_deq(const HostIndex& h, std::vector<float>* deq);

@@ -9,17 +9,48 @@
 
 namespace sgpu {
 
+// ---- DotVByte forward index (SGPU_VAL_DOTVBYTE; search_kernel.inc: VT_DVB) ---------------------------------------
+// A document is stored as eight 12-bit component gaps per 8-element slice when its first component and every gap
+// are below 4096; otherwise it keeps the raw (fixed-u8) record form and its refs carry kDvbRawBit in the length field.
+static constexpr uint64_t kDvbRawBit = 0x8000;
+void pack_dvb_raw_flags(const HostIndex& h, std::vector<uint8_t>* out) {
+  std::vector<uint8_t>& raw = *out;
+  raw.assign(h.value_type == SGPU_VAL_DOTVBYTE ? h.n_docs : 0, 0);
+  if (raw.empty()) return;
+  const uint16_t* comps = (const uint16_t*)h.fwd_comps.data();
+#pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
+  for (int64_t doc = 0; doc < (int64_t)h.n_docs; ++doc) {
+    uint32_t prev = 0;
+    uint8_t r = 0;
+    for (uint64_t i = h.fwd_offsets[(size_t)doc]; i < h.fwd_offsets[(size_t)doc + 1]; ++i) {
+      if ((uint32_t)comps[i] - prev >= 4096u) r = 1;
+      prev = comps[i];
+    }
+    raw[(size_t)doc] = r;
+  }
+}
+// bytes of a document's record (before the padding to 16)
+static inline uint64_t record_bytes(const HostIndex& h, const std::vector<uint8_t>& raw, uint64_t doc, uint64_t len) {
+  const uint64_t npad = (len + 7) & ~7ull;
+  if (h.value_type == SGPU_VAL_DOTVBYTE && !raw[doc]) {
+    const uint64_t ns = npad / 8;
+    return ((ns * 12 + 7) & ~7ull) + ns * 8;   // [ns x 12 B gaps][pad to 8][ns x 8 B codes]
+  }
+  return npad * (h.comp_width + h.val_bytes());
+}
+static inline uint64_t ref_len_field(const HostIndex& h, const std::vector<uint8_t>& raw, uint64_t doc, uint64_t len) {
+  return len | ((h.value_type == SGPU_VAL_DOTVBYTE && raw[doc]) ? kDvbRawBit : 0ull);
+}
+
 // Record offsets in 16-byte units. A record is moved to the next `line16`-unit line only if it would
 // otherwise touch more lines than its size needs (a sequential prefix: cheap, one pass).
-void pack_record_offsets(const HostIndex& h, uint64_t line16, std::vector<uint64_t>* out) {
-  const uint32_t cw = h.comp_width, vb = h.val_bytes();
+void pack_record_offsets(const HostIndex& h, const std::vector<uint8_t>& raw, uint64_t line16, std::vector<uint64_t>* out) {
   std::vector<uint64_t>& rec_off16 = *out;
   rec_off16.assign(h.n_docs + 1, 0);
   uint64_t cur = 0;
   for (uint64_t doc = 0; doc < h.n_docs; ++doc) {
     const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
-    const uint64_t npad = (len + 7) & ~7ull;
-    const uint64_t size16 = (npad * (cw + vb) + 15) / 16;
+    const uint64_t size16 = (record_bytes(h, raw, doc, len) + 15) / 16;
     const uint64_t in_line = cur % line16;
     if (size16 && (in_line + size16 + line16 - 1) / line16 > (size16 + line16 - 1) / line16) cur += line16 - in_line;
     rec_off16[doc] = cur;
@@ -31,7 +62,7 @@ void pack_record_offsets(const HostIndex& h, uint64_t line16, std::vector<uint64
 // Document records: [npad components][npad values (f16, or u8 codes)], npad = len rounded up to 8, the
 // record padded to 16 bytes. Padding components carry the sentinel id `dim` (never a query component)
 // when it is representable; their values are 0.
-void pack_records(const HostIndex& h, const std::vector<uint64_t>& rec_off16, std::vector<uint8_t>* out) {
+void pack_records(const HostIndex& h, const std::vector<uint8_t>& raw, const std::vector<uint64_t>& rec_off16, std::vector<uint8_t>* out) {
   const uint32_t cw = h.comp_width, vb = h.val_bytes();
   std::vector<uint8_t>& fwd = *out;
   fwd.assign(std::max<uint64_t>(rec_off16[h.n_docs] * 16, 16), 0);
@@ -40,6 +71,29 @@ void pack_records(const HostIndex& h, const std::vector<uint64_t>& rec_off16, st
     const uint64_t s0 = h.fwd_offsets[(size_t)doc], len = h.fwd_offsets[(size_t)doc + 1] - s0;
     const uint64_t npad = (len + 7) & ~7ull;
     uint8_t* rec = fwd.data() + rec_off16[(size_t)doc] * 16;
+    if (h.value_type == SGPU_VAL_DOTVBYTE && !raw[(size_t)doc]) {
+      // eight 12-bit gaps per slice in three dwords: g0 = w0[0:12) g1 = w0[12:24) g2 = w0[24:32) | w1[0:4) << 8
+      // g3 = w1[4:16) g4 = w1[16:28) g5 = w1[28:32) | w2[0:8) << 4 g6 = w2[8:20) g7 = w2[20:32); the gap of an
+      // element to its predecessor (the document's first element: to 0); padding elements: gap 0, code 0
+      const uint16_t* comps = (const uint16_t*)h.fwd_comps.data() + s0;
+      const uint64_t ns = npad / 8;
+      uint32_t* gw = (uint32_t*)rec;
+      uint8_t* codes = rec + ((ns * 12 + 7) & ~7ull);
+      uint32_t prev = 0;
+      for (uint64_t sl = 0; sl < ns; ++sl) {
+        uint32_t g[8];
+        for (uint64_t i = 0; i < 8; ++i) {
+          const uint64_t e = sl * 8 + i;
+          g[i] = e < len ? (uint32_t)comps[e] - prev : 0u;
+          if (e < len) prev = comps[e];
+        }
+        gw[3 * sl + 0] = g[0] | (g[1] << 12) | (g[2] << 24);
+        gw[3 * sl + 1] = (g[2] >> 8) | (g[3] << 4) | (g[4] << 16) | (g[5] << 28);
+        gw[3 * sl + 2] = (g[5] >> 4) | (g[6] << 8) | (g[7] << 20);
+      }
+      std::memcpy(codes, h.fwd_codes.data() + s0, len);
+      continue;
+    }
     std::memcpy(rec, h.fwd_comps.data() + s0 * cw, len * cw);
     if (vb == 2) std::memcpy(rec + npad * cw, h.fwd_vals.data() + s0, len * 2);
     else std::memcpy(rec + npad * cw, h.fwd_codes.data() + s0, len);
@@ -52,8 +106,7 @@ void pack_records(const HostIndex& h, const std::vector<uint64_t>& rec_off16, st
 }
 
 // Block-major store: bsize[b] = 16-byte units before block b (every block starts on a 128-byte line).
-void pack_block_sizes(const HostIndex& h, std::vector<uint64_t>* out) {
-  const uint32_t cw = h.comp_width, vb = h.val_bytes();
+void pack_block_sizes(const HostIndex& h, const std::vector<uint8_t>& raw, std::vector<uint64_t>* out) {
   const uint64_t nb = h.n_blocks();
   std::vector<uint64_t>& bsize = *out;
   bsize.assign(nb + 1, 0);
@@ -63,7 +116,7 @@ void pack_block_sizes(const HostIndex& h, std::vector<uint64_t>* out) {
     for (uint64_t p = h.block_post_start[(size_t)b]; p < h.block_post_start[(size_t)b + 1]; ++p) {
       const uint32_t doc = h.post_doc[p];
       const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
-      u += (((len + 7) & ~7ull) * (cw + vb) + 15) / 16;
+      u += (record_bytes(h, raw, doc, len) + 15) / 16;
     }
     bsize[(size_t)b + 1] = (u + 7) & ~7ull;
   }
@@ -73,9 +126,8 @@ void pack_block_sizes(const HostIndex& h, std::vector<uint64_t>* out) {
 // Posting refs (record offset / 16) << 16 | len, the reference's PackedPostingBlock (src/posting_list.rs:32-60).
 // Block-major: inside a block the records are grouped by the scoring loop's length class (<= 128 elements
 // first, longer ones after; posting order within a class), so consecutive items of a class are adjacent records.
-void pack_post_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, const std::vector<uint64_t>& bsize,
-                    bool block_major, uint64_t blk_base, std::vector<uint64_t>* out) {
-  const uint32_t cw = h.comp_width, vb = h.val_bytes();
+void pack_post_refs(const HostIndex& h, const std::vector<uint8_t>& raw, const std::vector<uint64_t>& rec_off16,
+                    const std::vector<uint64_t>& bsize, bool block_major, uint64_t blk_base, std::vector<uint64_t>* out) {
   const uint64_t nb = h.n_blocks();
   std::vector<uint64_t>& pref = *out;
   pref.assign(h.n_postings(), 0);
@@ -87,18 +139,19 @@ void pack_post_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, 
         const uint32_t doc = h.post_doc[p];
         const uint64_t len = h.fwd_offsets[doc + 1] - h.fwd_offsets[doc];
         if ((len > 128) != (cls == 1)) continue;
-        pref[p] = ((block_major ? cur : rec_off16[doc]) << 16) | len;
-        cur += (((len + 7) & ~7ull) * (cw + vb) + 15) / 16;
+        pref[p] = ((block_major ? cur : rec_off16[doc]) << 16) | ref_len_field(h, raw, doc, len);
+        cur += (record_bytes(h, raw, doc, len) + 15) / 16;
       }
   }
 }
 
-void pack_doc_refs(const HostIndex& h, const std::vector<uint64_t>& rec_off16, std::vector<uint64_t>* out) {
+void pack_doc_refs(const HostIndex& h, const std::vector<uint8_t>& raw, const std::vector<uint64_t>& rec_off16, std::vector<uint64_t>* out) {
   std::vector<uint64_t>& dref = *out;
   dref.assign(h.n_docs, 0);
 #pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
   for (int64_t doc = 0; doc < (int64_t)h.n_docs; ++doc)
-    dref[(size_t)doc] = (rec_off16[(size_t)doc] << 16) | (h.fwd_offsets[(size_t)doc + 1] - h.fwd_offsets[(size_t)doc]);
+    dref[(size_t)doc] = (rec_off16[(size_t)doc] << 16) |
+                        ref_len_field(h, raw, (uint64_t)doc, h.fwd_offsets[(size_t)doc + 1] - h.fwd_offsets[(size_t)doc]);
 }
 
 void pack_narrow(const std::vector<uint64_t>& v, std::vector<uint32_t>* out) {

@@ -466,17 +466,20 @@ class SeismicIndexLV(_IndexBase):
 class SeismicIndexDotVByte(_IndexBase):
     """The reference's compressed index (src/pylib/dotvbyte.rs:20-36): the standard u16/f16 index is
     built first and its forward index is then converted (`convert_dataset_into`, :208-213) - here to
-    fixed-u8 document values, 3 bytes per component instead of 4 in HBM. Same query API and results
-    type as SeismicIndex; scores differ by the 8-bit quantisation of the document values. u16
-    components only, as in the reference. (vectorium's DotVByteFixedU8Encoder is not in the reference
-    tree: the fixed-point step is restated, see include/seismic_hip.h; its variable-byte component
-    stream is a lossless storage codec without arithmetic and is not reproduced.)"""
+    SGPU_VAL_DOTVBYTE: fixed-u8 document values and a compressed component stream (eight 12-bit gaps per
+    8-element slice), 2.5 bytes per component in HBM instead of 4. Same query API and results type as
+    SeismicIndex; scores differ by the 8-bit quantisation of the document values. u16 components only, as
+    in the reference. (vectorium's DotVByteFixedU8Encoder is not in the reference tree: the fixed-point
+    step and the layout of the lossless component stream are restated, see include/seismic_hip.h - parity
+    unpinned; results are bit-identical to the fixed-u8 index, which the tests assert.)
+    `component_stream=False` keeps the raw u16 components (SGPU_VAL_FIXEDU8, 3 bytes per component)."""
     _CW = 2
 
-    def __init__(self, native, token_map, doc_ids, contents=None, device=0, upload=True):
-        from ._abi import SGPU_VAL_FIXEDU8
-        if native.desc.value_type != SGPU_VAL_FIXEDU8:
-            native = native.convert(SGPU_VAL_FIXEDU8)
+    def __init__(self, native, token_map, doc_ids, contents=None, device=0, upload=True, component_stream=True):
+        from ._abi import SGPU_VAL_DOTVBYTE, SGPU_VAL_FIXEDU8
+        want = SGPU_VAL_DOTVBYTE if component_stream else SGPU_VAL_FIXEDU8
+        if native.desc.value_type != want:
+            native = native.convert(want)
         super().__init__(native, token_map, doc_ids, contents, device, upload)
 
 

@@ -459,3 +459,75 @@ def test_cpu_quota_of_the_container_caps_the_default_host_team(tmp_path, monkeyp
         assert L.sgpu_debug_host_threads() == (free if want is None else min(free, 2))
     monkeypatch.setenv("SGPU_HOST_THREADS", "5")   # the override wins over everything
     assert L.sgpu_debug_host_threads() == 5
+
+
+def test_dotvbyte_records_decode_to_their_documents(tmp_path):
+    """SGPU_VAL_DOTVBYTE: every record the product packs (eight 12-bit component gaps per slice, raw fallback for a
+    document with a first component or a gap >= 4096) decodes - by the oracle's independent restatement of the layout -
+    to the document it was packed from; padding elements leave component and score alone; the conversions and the
+    index file keep codes and components; what the format refuses is refused loudly."""
+    rng = np.random.default_rng(11)
+    dim = 60000
+    lens = [0, 1, 7, 8, 9, 16, 127, 128, 129, 255, 256, 257, 300, 1000]
+    vecs = []
+    for d in range(600):
+        n = lens[d % len(lens)]
+        hi = [3000, 9000, dim][d % 3]            # all gaps small / some wide / mostly wide for short documents
+        c = np.sort(rng.choice(hi, min(n, hi), replace=False)).astype(np.uint32)
+        if d == 5 and n:
+            c[0] = 0                              # first component 0
+        if d % 50 == 3 and n > 1:
+            c = np.sort(np.unique(np.concatenate([c[:-1], [dim - 1]]))).astype(np.uint32)   # a last gap that may be wide
+        vecs.append((c, (rng.exponential(0.5, len(c)) + 0.01).astype(np.float32)))
+    # exactly at the limits of a 12-bit gap: first component 4095 (fits) and 4096 (raw), gap 4095 / 4096
+    vecs.append((np.array([4095, 4095 + 4095], np.uint32), np.array([1.0, 2.0], np.float32)))
+    vecs.append((np.array([4096, 4097], np.uint32), np.array([1.0, 2.0], np.float32)))
+    vecs.append((np.array([10, 10 + 4096], np.uint32), np.array([1.0, 2.0], np.float32)))
+    off, comps, vals = orc.csr(vecs)
+    f16 = _native.NativeIndex.build(2, dim, off, comps, vals, BuildConfig.defaults(n_postings=50))
+    dvb = f16.convert(2)
+    u8 = f16.convert(1)
+    d = dvb.desc
+    assert d.value_type == 2 and d.val_scale == u8.desc.val_scale and d.nnz == u8.desc.nnz
+    a2, a1 = orc.desc_arrays(d), orc.desc_arrays(u8.desc)
+    assert np.array_equal(a2["fwd_vals"], a1["fwd_vals"]) and np.array_equal(a2["fwd_comps"], a1["fwd_comps"])
+    L = _native.lib()
+    L.sgpu_debug_pack_forward.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+    need = ctypes.c_uint64(0)
+    assert L.sgpu_debug_pack_forward(dvb.h, None, 0, None, ctypes.byref(need)) == 0
+    fwd = np.zeros(need.value + 16, np.uint8)
+    refs = np.zeros(d.n_docs, np.uint64)
+    assert L.sgpu_debug_pack_forward(dvb.h, fwd.ctypes.data_as(ctypes.c_void_p), need.value, refs.ctypes.data_as(ctypes.c_void_p), ctypes.byref(need)) == 0
+    need_u8 = ctypes.c_uint64(0)
+    assert L.sgpu_debug_pack_forward(u8.h, None, 0, None, ctypes.byref(need_u8)) == 0
+    assert need.value < need_u8.value            # the stream is smaller than the raw components
+    O = orc.lib()
+    O.orc_dvb_decode_record.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    fo = a2["fwd_offsets"]
+    n_raw = 0
+    for doc in range(int(d.n_docs)):
+        ref = int(refs[doc])
+        ln, raw, off16 = ref & 0x7fff, (ref >> 15) & 1, ref >> 16
+        s, e = int(fo[doc]), int(fo[doc + 1])
+        assert ln == e - s
+        c_doc = a2["fwd_comps"][s:e].astype(np.int64)
+        wide = ln > 0 and (int(c_doc[0]) >= 4096 or (ln > 1 and int(np.diff(c_doc).max()) >= 4096))
+        assert bool(raw) == wide, (doc, raw, c_doc[:4])
+        n_raw += raw
+        co, vo = np.zeros(max(ln, 1), np.uint16), np.zeros(max(ln, 1), np.uint8)
+        rc = O.orc_dvb_decode_record(fwd.ctypes.data + off16 * 16, ln, raw, co.ctypes.data_as(ctypes.c_void_p), vo.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, (doc, rc)
+        assert np.array_equal(co[:ln], a2["fwd_comps"][s:e]) and np.array_equal(vo[:ln], a2["fwd_vals"][s:e]), doc
+    assert 0 < n_raw < d.n_docs                   # both record forms occur
+    # the index file keeps the value type; DotVByte <-> fixed-u8 <-> f16 conversions keep the codes
+    path = str(tmp_path / "dvb.idx")
+    dvb.save(path)
+    back = _native.NativeIndex.load(path)
+    assert back.desc.value_type == 2 and np.array_equal(orc.desc_arrays(back.desc)["fwd_vals"], a2["fwd_vals"])
+    again = dvb.convert(1)   # (kept alive: desc_arrays views the index's own memory)
+    assert again.desc.value_type == 1 and np.array_equal(orc.desc_arrays(again.desc)["fwd_vals"], a1["fwd_vals"])
+    # u32 components have no DotVByte form (the reference's class is u16-only)
+    w = _native.NativeIndex.build(4, 70000, *random_dataset(3, 50, 70000))
+    with pytest.raises(_native.SeismicHipError) as ei:
+        w.convert(2)
+    assert ei.value.status == 1

@@ -90,7 +90,7 @@ def test_dotvbyte_class_through_the_python_api():
     path = os.path.join(GOLD, "toy", "documents.jsonl")
     ix = seismic_amd.SeismicIndexDotVByte.build(path)
     ref = seismic_amd.SeismicIndex.build(path)
-    assert ix._ix.desc.value_type == 1 and ix.len == ref.len == 20 and ix.dim == ref.dim
+    assert ix._ix.desc.value_type == 2 and ix.len == ref.len == 20 and ix.dim == ref.dim
     qids, vecs, _ = seismic_amd.index.read_jsonl(os.path.join(GOLD, "toy", "queries.jsonl"))
     comps = [np.array(list(v.keys()), dtype=seismic_amd.get_seismic_string()) for v in vecs]
     vals = [np.array(list(v.values()), dtype=np.float32) for v in vecs]
@@ -110,7 +110,7 @@ def test_dotvbyte_graph_is_the_graph_of_the_index_as_built():
     ref = seismic_amd.SeismicIndex.build(path, nknn=3)
     a, da = ix._ix.get_knn()
     b, db = ref._ix.get_knn()
-    assert ix._ix.desc.value_type == 1 and da == db == 3 and len(a) == len(b) > 0
+    assert ix._ix.desc.value_type == 2 and da == db == 3 and len(a) == len(b) > 0
     assert np.array_equal(a, b)
     qids, vecs, _ = seismic_amd.index.read_jsonl(os.path.join(GOLD, "toy", "queries.jsonl"))
     comps = [np.array(list(v.keys()), dtype=seismic_amd.get_seismic_string()) for v in vecs]
@@ -142,3 +142,85 @@ def test_fixed_u8_values_with_u32_components():
         finally:
             for k_ in env:
                 os.environ.pop(k_, None)
+
+
+def _gappy_dataset(seed, n_docs, dim):
+    """Documents that exercise every record form of the DotVByte layout: lengths 0, 1, 7, 8, 9, 127 ... 300 (one, two
+    and more passes of the 16-lane groups), vocabularies wide enough that some documents have a first component or a
+    gap >= 4096 (raw fallback) and some do not."""
+    rng = np.random.default_rng(seed)
+    lens = [0, 1, 7, 8, 9, 16, 120, 127, 128, 129, 255, 256, 257, 300, 390]
+    vecs = []
+    for d in range(n_docs):
+        n = lens[d % len(lens)] if d % 3 else int(rng.integers(1, 200))
+        if d % 5 == 0:      # dense low ids: every gap small
+            c = np.sort(rng.choice(min(dim, 3000), min(n, 3000), replace=False))
+        else:               # anywhere in the vocabulary: wide gaps for short documents, small ones for long documents
+            c = np.sort(rng.choice(dim, n, replace=False))
+        vecs.append((c.astype(np.uint32), (rng.exponential(0.5, n) + 0.01).astype(np.float32)))
+    return orc.csr(vecs)
+
+
+@pytest.mark.parametrize("env", [dict(), dict(SGPU_NO_DENSE="1"), dict(SGPU_FORCE_HASH="1"), dict(SGPU_BLOCK="1024"),
+                                 dict(SGPU_FWD_LAYOUT="doc"), dict(SGPU_COOP="force", SGPU_COOP_MIN_ITEMS="0"),
+                                 dict(SGPU_ITEMS_MAX="64", SGPU_ITEMS_INIT="16", SGPU_ITEMS_MIN="16", SGPU_RBLOCKS="1")])
+def test_dotvbyte_component_stream_is_lossless_on_the_gpu(env, monkeypatch):
+    """SGPU_VAL_DOTVBYTE (fixed-u8 values + eight 12-bit component gaps per slice, raw fallback per document): the
+    codec is lossless, so every search returns the fixed-u8 index's rows bit for bit - and the oracle's."""
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    dim = 20000
+    off, comps, vals = _gappy_dataset(7, 6000, dim)
+    f16 = _native.NativeIndex.build(2, dim, off, comps, vals,
+                                    BuildConfig.defaults(n_postings=300, centroid_fraction=0.2, summary_energy=0.5, max_fraction=6.0))
+    u8 = f16.convert(1).upload(0)
+    dvb = f16.convert(2)
+    assert dvb.desc.value_type == 2 and dvb.convert(1).desc.value_type == 1
+    dvb.upload(0)
+    assert dvb.device_bytes() < u8.device_bytes()
+    rng = np.random.default_rng(8)
+    qs = []
+    for i in range(64):
+        n = int(rng.integers(3, 70))
+        c = np.sort(rng.choice(dim if i % 2 else 3000, n, replace=False)).astype(np.uint32)
+        qs.append((c, (rng.exponential(0.5, n) + 0.01).astype(np.float32)))
+    q = orc.csr(qs)
+    for (k, qcut, hf, srt) in [(10, 4, 1.0, False), (10, 10, 0.7, True), (1, 3, 0.9, False), (100, 8, 0.8, True), (300, 5, 0.0, False)]:
+        got = dvb.batch_search(*q, k, qcut, hf, srt)
+        _same(got, u8.batch_search(*q, k, qcut, hf, srt))
+        _same(got, orc.batch_search(dvb.desc, *q, k, qcut, hf, srt)[:3])
+    b = _native.DeviceBatch(dvb, *q, 10)
+    b.run(10, 4, 1.0, False)
+    g1 = b.fetch(10)
+    b.run_counted(10, 4, 1.0, False)
+    _same(g1, b.fetch(10))
+    # kNN refinement reads the document-major records of the same layout
+    dvb.build_knn(3)
+    nb = orc.knn_build(dvb.desc, 3)
+    assert np.array_equal(dvb.get_knn()[0], nb)
+    orc.knn_attach(nb, 3)
+    try:
+        exp = orc.batch_search(dvb.desc, *q, 10, 3, 0.9, False, n_knn=2)[:3]
+    finally:
+        orc.knn_attach(None, 0)
+    _same(dvb.batch_search(*q, 10, 3, 0.9, False, n_knn=2), exp)
+
+
+def test_dotvbyte_at_scale_matches_fixed_u8():
+    """Synthetic SPLADE shape, 1M docs (BASELINE configs[1] size), 1000 queries: rows identical to the fixed-u8 index
+    in both traversal modes and through single-query (cooperative) launches; 2.5 instead of 3 bytes per element."""
+    dim, n_docs, nq = 30_000, 1_000_000, 1000
+    docs = _native.synth(n_docs, dim, 42, 0)
+    f16 = _native.NativeIndex.build(2, dim, *docs, BuildConfig.defaults(n_postings=2000, centroid_fraction=0.2,
+                                                                         summary_energy=0.5, max_fraction=6.0, use_device=1))
+    u8 = f16.convert(1).upload(0)
+    dvb = f16.convert(2).upload(0)
+    q = _native.synth(nq, dim, 43, 1, docs)
+    for srt in (False, True):
+        want = u8.batch_search(*q, 10, 4, 1.0, srt)
+        _same(dvb.batch_search(*q, 10, 4, 1.0, srt), want)
+    _same(dvb.batch_search(*q, 10, 4, 1.0, False), orc.batch_search(dvb.desc, *q, 10, 4, 1.0, False, tuned=True)[:3])
+    want = u8.batch_search(*q, 10, 4, 1.0, False)
+    sc, ids, n, _, _ = dvb.search_sequential(q[0][:101], q[1], q[2], 10, 4, 1.0, False)
+    _same((sc, ids, n), tuple(x[:100] for x in want))
+    assert dvb.device_bytes() < 0.9 * u8.device_bytes()
