@@ -89,8 +89,10 @@ def parse_args():
                     help="N>1, strong scaling: skip the extra replicas (weak scaling) measurement")
     ap.add_argument("--all-legs", action="store_true",
                     help="N>1: also run the single-GPU legs (end to end, latency, recall) on rank 0")
-    ap.add_argument("--host-threads", type=int, default=2,
-                    help="request threads issuing the timed sgpu_batch_search calls (each call is synchronous)")
+    ap.add_argument("--host-threads", type=int, default=0,
+                    help="request threads issuing the timed sgpu_batch_search calls (each call is synchronous); 0 = by the "
+                         "size of a call: 2 for calls of 2500 queries or more, 3 for smaller ones (one rank's shard of a "
+                         "10 000-query batch on 8 GPUs is 1250 queries: profiles/r04_shard_probe.txt)")
     ap.add_argument("--target-recall", default="0.90,0.95,0.99",
                     help="operating points: for each recall@k the cheapest (query_cut, heap_factor, first_sorted) on this "
                          "index that reaches it on the sample (empty string = skip)")
@@ -342,7 +344,9 @@ def main():
     # every batch's result rows (the entry point writes into them; no allocation inside the timed region)
     outs = [(np.zeros((my_q, args.k), np.float32), np.zeros((my_q, args.k), np.uint64), np.zeros(max(my_q, 1), np.uint32))
             for _ in range(n_batches)]
-    n_threads = max(1, args.host_threads)
+    # (a call returns its rows before its thread issues the next one; the host side of a small call - validation, launch
+    # plan, staging, copies: ~0.3 us per query - is hidden by the other threads' kernels)
+    n_threads = args.host_threads if args.host_threads > 0 else (2 if my_q >= 2500 else 3)
 
     def entry_call(i):
         b = i % n_batches

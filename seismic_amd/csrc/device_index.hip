@@ -390,6 +390,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     d->view.dim = (uint32_t)h.dim;
     d->view.n_docs = (uint32_t)h.n_docs;
     d->view.n_bitmap_words = (uint32_t)((h.n_docs + 31) / 32);
+    d->view.n_postings_lt_2g = h.n_postings() < (1ull << 31) ? 1u : 0u;
     // ---- block-count statistics for LDS sizing
     d->list_nb.resize(h.dim);
     d->list_np.resize(h.dim);

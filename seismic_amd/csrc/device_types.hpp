@@ -30,6 +30,7 @@ struct DevView {
   uint64_t knn_total;
   uint32_t knn_dim;
   uint32_t dim, n_docs, n_bitmap_words;
+  uint32_t n_postings_lt_2g;          // posting indices fit 31 bits (lazy document ids keep one in it_doc next to the visited bit)
 };
 
 struct BatchView {

@@ -127,3 +127,37 @@ def test_accumulation_order_tolerance_at_full_size(capsys):
               "explained by a near-tie; max |ds|/max(1,|s|) = %.2e" % (nq, differ, unexplained, max_rel))
     assert unexplained == 0
     assert differ <= nq // 100
+
+
+def test_c3_operating_points_full_size_bit_exact(monkeypatch):
+    """The parameters the bench quotes its fixed-recall numbers on (profiles/operating_points.json), at the metric's
+    size: 8.8M docs indexed with n_postings 3000 / max_fraction 4 (the 0.95-recall index), query_cut 10 (the lists are
+    walked in groups of four: stage-1 row tables per group) and query_cut 16 with first_sorted both ways (r03's 0.95
+    point), bit-identical to the oracle; the same index forced through the cooperative variant (every launch, owners go
+    wide without waiting for helpers) and as a DotVByte index (rows identical to the fixed-u8 index's)."""
+    dim, n_docs, nq = 30_000, 8_800_000, 1000
+    docs = _native.synth(n_docs, dim, 42, 0)
+    ix = _native.NativeIndex.build(2, dim, *docs, BuildConfig.defaults(n_postings=3000, centroid_fraction=0.2,
+                                                                        summary_energy=0.5, max_fraction=4.0, use_device=1))
+    ix.upload(0)
+    q = _native.synth(nq, dim, 43, 1, docs)
+    del docs
+    want = {}
+    for cut, hf, srt in ((10, 1.0, False), (16, 1.0, False), (16, 1.0, True), (6, 0.9, False)):
+        want[(cut, hf, srt)] = orc.batch_search(ix.desc, *q, 10, cut, hf, srt, tuned=True)[:3]
+        _same(ix.batch_search(*q, 10, cut, hf, srt), want[(cut, hf, srt)])
+    monkeypatch.setenv("SGPU_COOP", "force")
+    for key in ((10, 1.0, False), (16, 1.0, True)):
+        _same(ix.batch_search(*q, 10, *key), want[key])
+    monkeypatch.setenv("SGPU_COOP", "1")
+    sc, ids, n, _, _ = ix.search_sequential(q[0][:61], q[1], q[2], 10, 10, 1.0, False)
+    _same((sc, ids, n), tuple(a[:60] for a in want[(10, 1.0, False)]))
+    # the DotVByte index of the same collection: the fixed-u8 index's rows, 2.5 instead of 3 bytes per element
+    u8 = ix.convert(1).upload(0)
+    ref = u8.batch_search(*q, 10, 10, 1.0, False)
+    _same(ref, orc.batch_search(u8.desc, *q, 10, 10, 1.0, False, tuned=True)[:3])
+    u8_bytes = u8.device_bytes()
+    u8.close()
+    dvb = ix.convert(2).upload(0)
+    _same(dvb.batch_search(*q, 10, 10, 1.0, False), ref)
+    assert dvb.device_bytes() < 0.9 * u8_bytes

@@ -17,7 +17,7 @@ ap.add_argument("--max-fraction", type=float, default=6.0)
 ap.add_argument("--query-cut", type=int, default=4)
 ap.add_argument("--heap-factor", type=float, default=1.0)
 ap.add_argument("--shards", default="1,2,4,8")
-ap.add_argument("--threads", default="1,2,3")
+ap.add_argument("--threads", default="1,2,3,4")
 ap.add_argument("--batches", type=int, default=6)
 ap.add_argument("--reps", type=int, default=3)
 a = ap.parse_args()
@@ -37,12 +37,26 @@ def shard(b, n, r):
     return (off[lo:hi + 1] - off[lo]).astype(np.uint64), qc[o0:o1], qv[o0:o1]
 
 
+import ctypes
+L = _native.lib()
+L.sgpu_debug_call_timing.argtypes = [ctypes.c_void_p]
+PH = ["validate+plan", "staging", "enqueue_h2d", "configure+launch", "enqueue_d2h", "wait", "copy_out"]
 base = None
 for n in [int(x) for x in a.shards.split(",")]:
     # rank 0's shard of every batch (a rank sees one shard per step)
     calls_in = [shard(b, n, 0) for b in range(a.batches)]
     nq = len(calls_in[0][0]) - 1
     outs = [(np.zeros((nq, 10), np.float32), np.zeros((nq, 10), np.uint64), np.zeros(nq, np.uint32)) for _ in calls_in]
+    # host-side phases of one call (single thread, summed over the call's chunks)
+    buf = (ctypes.c_double * 8)()
+    L.sgpu_debug_call_timing(ctypes.addressof(buf))
+    for j in range(2 * len(calls_in)):
+        if j == len(calls_in):
+            for i in range(8):
+                buf[i] = 0.0
+        ix.batch_search(*calls_in[j % len(calls_in)], 10, a.query_cut, a.heap_factor, False, out=outs[j % len(calls_in)])
+    L.sgpu_debug_call_timing(None)
+    print("shards %d: host phases per call (us): %s" % (n, ", ".join("%s %.0f" % (PH[i], buf[i] / len(calls_in)) for i in range(7))), flush=True)
     for T in [int(x) for x in a.threads.split(",")]:
         best = None
         for rep in range(a.reps + 1):
