@@ -59,8 +59,9 @@ def main():
     targets = [float(x) for x in a.targets.split(",") if x]
     if a.summarise:
         rows = [json.loads(l) for l in open(a.summarise) if l.strip().startswith("{")]
-        print(json.dumps({"targets": summarise(rows, targets), "points": len([r for r in rows if "recall" in r]),
-                          "indexes": [r for r in rows if "index_built" in r]}, indent=1))
+        gen = next((r for r in rows if "generated_s" in r), {})
+        print(json.dumps({"docs": gen.get("docs"), "dim": gen.get("dim"), "targets": summarise(rows, targets),
+                          "points": len([r for r in rows if "recall" in r]), "indexes": [r for r in rows if "index_built" in r]}, indent=1))
         return
     from seismic_amd import _native
     from seismic_amd._abi import BuildConfig
