@@ -727,7 +727,9 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
         uint32_t tc[kSmall];
         const uint32_t* sel = tc;
         size_t nl = 0;
-        if (query_cut <= kSmall) {
+        if (query_cut == 0) {
+          // (no list is walked: the reference's k_largest_by(0))
+        } else if (query_cut <= kSmall) {
           for (uint64_t i = qa; i < qe; ++i) {
             const int32_t key = total_key(h_val[i]);
             if (nl == query_cut && !(key > tk[nl - 1])) continue;

@@ -18,4 +18,4 @@ done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/calib_fetch" -o pmc -- "$REPO/tools/ubench/random_record_read" 8192 512 8 > "$OUT/calib.txt" 2>&1
 python "$REPO/tools/pmc_summary.py" "$OUT" > "$OUT/summary.json"
 # the raw traces are large: keep only the CSV summaries
-find "$OUT" -name "*.db" -delete; find "$OUT" -name "*_kernel_trace.csv" -size +2M -delete
+find "$OUT" -name "*.db" -delete; find "$OUT" -type f -size +400k -delete   # (gpurun copies at most 64 MiB back: summaries only)

@@ -19,5 +19,6 @@ tools/profile_traffic.sh gpurun_out/${TAG}_traffic_first_sorted --first-sorted 1
 mkdir -p gpurun_out/${TAG}_single
 (cd /tmp && TMPDIR=/tmp rocprofv3 --kernel-trace --stats --output-format csv -d "$REPO/gpurun_out/${TAG}_single/trace" -o trace -- \
    python "$REPO/tools/latency_probe.py" 8800000 > "$REPO/gpurun_out/${TAG}_single/latency_probe.txt" 2> "$REPO/gpurun_out/${TAG}_single/err.txt")
-find gpurun_out/${TAG}_single -name "*.db" -delete; find gpurun_out/${TAG}_single -name "*_kernel_trace.csv" -size +2M -delete
+find gpurun_out/${TAG}_single -name "*.db" -delete; find gpurun_out/${TAG}_single -type f -size +400k -delete
 ls gpurun_out/${TAG}_single/trace 2>/dev/null | head
+du -sh gpurun_out

@@ -13,7 +13,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_$C" -o pmc -- $BENCH --no-accounting --steps 4 --warmup 1 > "$OUT/pmc_$C.json" 2> "$OUT/pmc_$C.err"
 done
 python "$REPO/tools/pmc_summary.py" "$OUT" > "$OUT/summary.json"
-find "$OUT" -name "*.db" -delete; find "$OUT" -name "*_kernel_trace.csv" -size +2M -delete
+find "$OUT" -name "*.db" -delete; find "$OUT" -type f -size +400k -delete   # (gpurun copies at most 64 MiB back: summaries only)
 python - "$OUT" <<'PY'
 import json, sys
 out = sys.argv[1]
