@@ -41,6 +41,8 @@ sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
 int device_count();
 double*& call_timing();
+sgpu_status debug_plan(const HostIndex& h, const uint64_t* q_off, const uint32_t* comps, const float* vals, uint32_t nq,
+                       uint32_t query_cut, uint32_t* order_out, uint32_t* out3);
 uint32_t coop_trace_dump(DeviceIndex* d, uint64_t* out, uint32_t cap);
 const DeviceIndex* batch_replica(const sgpu_batch* b);
 sgpu_status device_index_set_knn(DeviceIndex* d, const std::vector<uint32_t>& knn, uint32_t knn_dim);
@@ -538,6 +540,14 @@ sgpu_status sgpu_debug_pack_forward(const sgpu_index* idx, uint8_t* out_fwd, uin
     return fail(SGPU_ENOMEM, "out of host memory");
   }
   return SGPU_OK;
+}
+
+// (not part of the boundary: the launch plan of a batch - processing order (longest expected first), out3 = {block dots a
+// query needs at most, largest list walked first, largest list walked}; needs no device)
+sgpu_status sgpu_debug_plan(const sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals, uint32_t nq,
+                            uint32_t query_cut, uint32_t* order_out, uint32_t* out3) {
+  if (!idx || !q_off || !order_out || !out3) return fail(SGPU_EINVAL, "null argument");
+  return debug_plan(idx->host, q_off, comps, vals, nq, query_cut, order_out, out3);
 }
 
 // (not part of the boundary: the calling thread's staged calls add the wall time of their host-side phases to

@@ -817,6 +817,30 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
   return SGPU_OK;
 }
 
+// (test hook, no device needed: the launch plan of a batch against a host index - the processing order, the block
+// dots a query needs at most, the largest list walked first / at all. sgpu_debug_plan, tests/test_abi_and_host.py)
+sgpu_status debug_plan(const HostIndex& h, const uint64_t* q_off, const uint32_t* comps, const float* vals, uint32_t nq,
+                       uint32_t query_cut, uint32_t* order_out, uint32_t* out3) {
+  DeviceIndex d;
+  d.comp_width = h.comp_width;
+  d.view.dim = (uint32_t)h.dim;
+  d.list_nb.resize(h.dim);
+  d.list_np.resize(h.dim);
+  for (uint64_t c = 0; c < h.dim; ++c) {
+    d.list_nb[c] = (uint32_t)(h.list_block_start[c + 1] - h.list_block_start[c]);
+    d.list_np[c] = (uint32_t)(h.block_post_start[h.list_block_start[c + 1]] - h.block_post_start[h.list_block_start[c]]);
+  }
+  sgpu_batch_plan pl;
+  env_refresh();
+  const sgpu_status st = make_plan(&d, q_off, comps, vals, nq, query_cut, &pl);
+  if (st != SGPU_OK) return st;
+  for (uint32_t i = 0; i < nq; ++i) order_out[i] = pl.order[i];
+  out3[0] = pl.dots_cap;
+  out3[1] = pl.max_nb;
+  out3[2] = pl.max_list_nb;
+  return SGPU_OK;
+}
+
 static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, const sgpu_batch_plan** out) {
   for (const auto& pl : b->plans)
     if (pl.query_cut == query_cut) {

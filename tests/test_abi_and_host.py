@@ -531,3 +531,50 @@ def test_dotvbyte_records_decode_to_their_documents(tmp_path):
     with pytest.raises(_native.SeismicHipError) as ei:
         w.convert(2)
     assert ei.value.status == 1
+
+
+def test_launch_plan_orders_and_sizes_a_batch_for_every_query_cut():
+    """The host-side launch plan (which lists each query will walk -> LDS need; longest-expected-first order) against a
+    numpy restatement of the kernel's selection rule (query_cut heaviest components by f32::total_cmp, ties by ascending
+    component), for query_cut 0 (no list: the reference's k_largest_by(0)), small cuts (insertion top-k) and cuts above 16
+    (the general path), on queries with tied and negative weights."""
+    rng = np.random.default_rng(21)
+    dim = 400
+    off, comps, vals = random_dataset(22, 3000, dim, nnz_lo=4, nnz_hi=80)
+    ix = _native.NativeIndex.build(2, dim, off, comps, vals, BuildConfig.defaults(n_postings=60, centroid_fraction=0.3))
+    a = orc.desc_arrays(ix.desc)
+    lbs, bps = a["list_block_start"].astype(np.int64), a["block_post_start"].astype(np.int64)
+    nb = np.diff(lbs)
+    npost = bps[lbs[1:]] - bps[lbs[:-1]]
+    qs = []
+    for i in range(200):
+        n = int(rng.integers(0, 60))
+        c = np.sort(rng.choice(dim, n, replace=False)).astype(np.uint32)
+        v = rng.choice([0.5, 1.0, 2.0, -1.0, 3.25], n).astype(np.float32) if i % 2 else rng.normal(0, 1, n).astype(np.float32)
+        qs.append((c, v))
+    q_off, qc, qv = orc.csr(qs)
+    L = _native.lib()
+    L.sgpu_debug_plan.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32,
+                                  ctypes.c_void_p, ctypes.c_void_p]
+
+    def total_key(x):   # f32::total_cmp as a signed integer key
+        b = np.float32(x).view(np.int32).astype(np.int64)
+        return int(b ^ (((b >> 31) & 0xffffffff) >> 1)) if b >= 0 else int(np.int32(b ^ 0x7fffffff))
+
+    for cut in (0, 1, 4, 16, 17, 40, 100):
+        order = np.zeros(len(qs), np.uint32)
+        out3 = np.zeros(3, np.uint32)
+        p = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+        assert L.sgpu_debug_plan(ix.h, p(q_off), p(qc), p(qv), len(qs), cut, p(order), p(out3)) == 0
+        cost, dots, first_nb, any_nb = [], 1, 0, 1
+        for c, v in qs:
+            sel = sorted(range(len(c)), key=lambda i: (-total_key(v[i]), int(c[i])))[:cut]
+            cost.append(int(npost[c[sel]].sum()) if sel else 0)
+            dots = max(dots, int(nb[c[sel]].sum()) if sel else 0)
+            if sel:
+                first_nb = max(first_nb, int(nb[c[sel[0]]]))
+                any_nb = max(any_nb, int(nb[c[sel]].max()))
+        assert sorted(order.tolist()) == list(range(len(qs)))                       # a permutation ...
+        want = sorted(range(len(qs)), key=lambda i: (-cost[i], i))                  # ... longest expected first, ties in input order
+        assert order.tolist() == want, cut
+        assert (int(out3[0]), int(out3[1]), int(out3[2])) == (dots, first_nb, any_nb), (cut, out3, dots, first_nb, any_nb)
