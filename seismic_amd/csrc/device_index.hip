@@ -894,13 +894,14 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   auto up = [](uint64_t x) { return (x + 15ull) & ~15ull; };
   LdsLayout L{};
   uint64_t o = 0;
-  L.q_comp = (uint32_t)o; o += up((uint64_t)qn * 4);
-  L.q_val = (uint32_t)o; o += up(((uint64_t)qn + 1) * 4);   // + the 0.0 slot non-matching components resolve to
-  L.q_sc = L.q_val;   // fixed-u8 documents: a second copy of the weights, scaled by val_scale
-  if (d->value_type != SGPU_VAL_F16) {
-    L.q_sc = (uint32_t)o;
+  // the weights the scoring loop reads come FIRST (LDS byte 0 is the 0.0 slot non-matching components resolve to)
+  L.q_sc = (uint32_t)o; o += up(((uint64_t)qn + 1) * 4);
+  L.q_val = L.q_sc;     // f16 documents: the query's values themselves
+  if (d->value_type != SGPU_VAL_F16) {   // fixed-u8 documents: q_sc is a second copy of the weights, scaled by val_scale
+    L.q_val = (uint32_t)o;
     o += up(((uint64_t)qn + 1) * 4);
   }
+  L.q_comp = (uint32_t)o; o += up((uint64_t)qn * 4);
   L.sel = (uint32_t)o; o += up((6ull * qc + 1) * 4);
   const uint64_t target = env_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
   // what the layout needs besides the row tables and the block dots (the dense lookup table where it may be used)
