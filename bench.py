@@ -394,7 +394,7 @@ def main():
     # every timed batch gets one extra pass with the visited set materialised (sgpu_batch_run_counted):
     # identical results, and work counters that exclude re-encountered documents exactly as the
     # reference does -> algorithmic bytes of each launch
-    # bytes per document element as stored: f16 2 + 2, fixed-u8 2 + 1, DotVByte 1.5 (eight 12-bit gaps per slice) + 1
+    # bytes per document element as stored: f16 2 + 2, fixed-u8 2 + 1, DotVByte 1.5 (12-byte slices of eight components) + 1
     val_bytes = 2 if args.value_type == "f16" else 1
     doc_comp_bytes = 1.5 if args.value_type == "dotvbyte" else None
     algo, counted_identical, results = [], True, {}
@@ -462,7 +462,7 @@ def main():
             "query": {"k": args.k, "query_cut": args.query_cut, "heap_factor": args.heap_factor,
                       "first_sorted": srt},
             "storage": "%s, u8-quantised block summaries" % (
-                "fixed-u8 document values, 12-bit component gaps (DotVByte forward index, 2.5 B per element)" if args.value_type == "dotvbyte"
+                "fixed-u8 document values, compressed component stream (DotVByte forward index, 2.5 B per element)" if args.value_type == "dotvbyte"
                 else "%s document values, u%d components" % (args.value_type, 8 * args.comp_width)),
             "parallelism": "index replicated, %s, no collective" % (
                 ("each batch of %d cut into %d contiguous shards" % (args.queries, world)) if scaling == "strong" and world > 1

@@ -83,9 +83,9 @@ typedef enum sgpu_status {
  *                    src/pylib/dotvbyte.rs:15-22, 208-213; `dotvbyte` value type of the CLI,
  *                    src/bin/perf_inverted_index.rs:110-126): the FIXEDU8 values PLUS a compressed
  *                    component stream. The host-side arrays of the descriptor are those of FIXEDU8 (u16
- *                    components, u8 codes); the compression is the HBM layout: eight 12-bit component gaps
- *                    per 8-element slice (three dwords instead of four), a document with a first component or
- *                    a gap >= 4096 keeps the raw record form. The reference's codec (vectorium's DotVByte, a
+ *                    components, u8 codes); the compression is the HBM layout: per 8-element slice three dwords
+ *                    instead of four (the first component in 16 bits, three 12-bit and four 11-bit gaps), a document
+ *                    with a gap that does not fit its field keeps the raw record form. The reference's codec (vectorium's DotVByte, a
  *                    variable-byte gap stream) is not in the tree: PARITY UNPINNED; it is lossless, so results
  *                    are those of the FIXEDU8 index - which is what the tests assert. u16 components only (as the
  *                    reference's class), documents of fewer than 32768 components. */

@@ -313,7 +313,7 @@ class DeviceBatch:
     def algorithmic_bytes(self, k, comp_width, val_bytes=2, doc_comp_bytes=None):
         """B_q of SURVEY.md 8(d), summed over the batch, from the kernel's own work counters
         (val_bytes: 2 for f16 document values, 1 for fixed-u8; doc_comp_bytes: bytes per document component as
-        stored, comp_width unless the component stream is compressed - 1.5 for DotVByte's 12-bit gaps)."""
+        stored, comp_width unless the component stream is compressed - 1.5 for DotVByte's 12-byte slices of eight components)."""
         st = self.fetch_stats().astype(np.int64)
         nnz_q = np.diff(self.q_off.astype(np.int64))
         per_elem = (comp_width if doc_comp_bytes is None else doc_comp_bytes) + val_bytes

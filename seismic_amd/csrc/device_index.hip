@@ -271,7 +271,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     // otherwise touch more lines than its size needs: at 16-byte alignment a 480-byte record straddles
     // ~4.75 lines, line-fitted 4.
     std::vector<uint64_t> rec_off16;
-    std::vector<uint8_t> dvb_raw;   // DotVByte: the documents that keep the raw record form (a gap >= 4096)
+    std::vector<uint8_t> dvb_raw;   // DotVByte: the documents that keep the raw record form (a gap too wide for its field)
     pack_dvb_raw_flags(h, &dvb_raw);
     {
       const char* env_line = std::getenv("SGPU_REC_LINE");
@@ -895,7 +895,8 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   LdsLayout L{};
   uint64_t o = 0;
   // the weights the scoring loop reads come FIRST (LDS byte 0 is the 0.0 slot non-matching components resolve to)
-  L.q_sc = (uint32_t)o; o += up(((uint64_t)qn + 1) * 4);
+  static_assert(kQscOffset == 0, "the weights come first");
+  L.q_sc = (uint32_t)o; o += up(((uint64_t)qn + 1) * 4);   // == kQscOffset: the kernel addresses the weights as byte + constant
   L.q_val = L.q_sc;     // f16 documents: the query's values themselves
   if (d->value_type != SGPU_VAL_F16) {   // fixed-u8 documents: q_sc is a second copy of the weights, scaled by val_scale
     L.q_val = (uint32_t)o;

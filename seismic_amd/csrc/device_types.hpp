@@ -128,6 +128,9 @@ struct KParams {
   float val_scale;       // fixed-u8 document values: value = code * val_scale (a power of two)
 };
 
+// The scoring loop's weights (q_sc, preceded by the 0.0 slot) sit at a FIXED offset of the dynamic LDS, so that the
+// scaled-byte dense lookup (search_kernel.inc: kScaledMaxNnz) can address them as `byte + constant`.
+enum { kQscOffset = 0 };
 struct LdsLayout {   // byte offsets into dynamic LDS, all multiples of 16
   uint32_t q_comp, q_val, q_sc, q_bits, q_rank, sel, rt_start, rt_mid, rt_pre, dots, order, uni, part, heap, st;
   uint32_t qc, qn;   // capacities: lists per query, components per query

@@ -10,9 +10,11 @@
 namespace sgpu {
 
 // ---- DotVByte forward index (SGPU_VAL_DOTVBYTE; search_kernel.inc: VT_DVB) ---------------------------------------
-// A document is stored as eight 12-bit component gaps per 8-element slice when its first component and every gap
-// are below 4096; otherwise it keeps the raw (fixed-u8) record form and its refs carry kDvbRawBit in the length field.
+// A document is stored as 12-byte slices of eight elements - the slice's first component in 16 bits, the gaps of
+// elements 1 .. 3 in 12 bits each, those of elements 4 .. 7 in 11 bits each - when every gap fits its field; otherwise
+// it keeps the raw (fixed-u8) record form and its refs carry kDvbRawBit in the length field.
 static constexpr uint64_t kDvbRawBit = 0x8000;
+static inline uint32_t dvb_gap_limit(uint64_t i) { return (i & 7) <= 3 ? 4096u : 2048u; }   // element i of its slice (i & 7 != 0)
 void pack_dvb_raw_flags(const HostIndex& h, std::vector<uint8_t>* out) {
   std::vector<uint8_t>& raw = *out;
   raw.assign(h.value_type == SGPU_VAL_DOTVBYTE ? h.n_docs : 0, 0);
@@ -20,12 +22,10 @@ void pack_dvb_raw_flags(const HostIndex& h, std::vector<uint8_t>* out) {
   const uint16_t* comps = (const uint16_t*)h.fwd_comps.data();
 #pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
   for (int64_t doc = 0; doc < (int64_t)h.n_docs; ++doc) {
-    uint32_t prev = 0;
+    const uint64_t s0 = h.fwd_offsets[(size_t)doc], s1 = h.fwd_offsets[(size_t)doc + 1];
     uint8_t r = 0;
-    for (uint64_t i = h.fwd_offsets[(size_t)doc]; i < h.fwd_offsets[(size_t)doc + 1]; ++i) {
-      if ((uint32_t)comps[i] - prev >= 4096u) r = 1;
-      prev = comps[i];
-    }
+    for (uint64_t i = s0 + 1; i < s1; ++i)
+      if (((i - s0) & 7) != 0 && (uint32_t)comps[i] - (uint32_t)comps[i - 1] >= dvb_gap_limit(i - s0)) r = 1;
     raw[(size_t)doc] = r;
   }
 }
@@ -72,24 +72,22 @@ void pack_records(const HostIndex& h, const std::vector<uint8_t>& raw, const std
     const uint64_t npad = (len + 7) & ~7ull;
     uint8_t* rec = fwd.data() + rec_off16[(size_t)doc] * 16;
     if (h.value_type == SGPU_VAL_DOTVBYTE && !raw[(size_t)doc]) {
-      // eight 12-bit gaps per slice in three dwords: g0 = w0[0:12) g1 = w0[12:24) g2 = w0[24:32) | w1[0:4) << 8
-      // g3 = w1[4:16) g4 = w1[16:28) g5 = w1[28:32) | w2[0:8) << 4 g6 = w2[8:20) g7 = w2[20:32); the gap of an
-      // element to its predecessor (the document's first element: to 0); padding elements: gap 0, code 0
+      // per slice three dwords = 96 bits: [0,16) first component | [16,28) [28,40) [40,52) gaps of elements 1 .. 3 |
+      // [52,63) [63,74) [74,85) [85,96) gaps of elements 4 .. 7; padding elements: gap 0, code 0
       const uint16_t* comps = (const uint16_t*)h.fwd_comps.data() + s0;
       const uint64_t ns = npad / 8;
       uint32_t* gw = (uint32_t*)rec;
       uint8_t* codes = rec + ((ns * 12 + 7) & ~7ull);
-      uint32_t prev = 0;
       for (uint64_t sl = 0; sl < ns; ++sl) {
         uint32_t g[8];
-        for (uint64_t i = 0; i < 8; ++i) {
+        g[0] = comps[sl * 8];
+        for (uint64_t i = 1; i < 8; ++i) {
           const uint64_t e = sl * 8 + i;
-          g[i] = e < len ? (uint32_t)comps[e] - prev : 0u;
-          if (e < len) prev = comps[e];
+          g[i] = e < len ? (uint32_t)comps[e] - (uint32_t)comps[e - 1] : 0u;
         }
-        gw[3 * sl + 0] = g[0] | (g[1] << 12) | (g[2] << 24);
-        gw[3 * sl + 1] = (g[2] >> 8) | (g[3] << 4) | (g[4] << 16) | (g[5] << 28);
-        gw[3 * sl + 2] = (g[5] >> 4) | (g[6] << 8) | (g[7] << 20);
+        gw[3 * sl + 0] = g[0] | (g[1] << 16) | (g[2] << 28);
+        gw[3 * sl + 1] = (g[2] >> 4) | (g[3] << 8) | (g[4] << 20) | (g[5] << 31);
+        gw[3 * sl + 2] = (g[5] >> 1) | (g[6] << 10) | (g[7] << 21);
       }
       std::memcpy(codes, h.fwd_codes.data() + s0, len);
       continue;

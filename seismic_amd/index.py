@@ -466,7 +466,7 @@ class SeismicIndexLV(_IndexBase):
 class SeismicIndexDotVByte(_IndexBase):
     """The reference's compressed index (src/pylib/dotvbyte.rs:20-36): the standard u16/f16 index is
     built first and its forward index is then converted (`convert_dataset_into`, :208-213) - here to
-    SGPU_VAL_DOTVBYTE: fixed-u8 document values and a compressed component stream (eight 12-bit gaps per
+    SGPU_VAL_DOTVBYTE: fixed-u8 document values and a compressed component stream (12 bytes per
     8-element slice), 2.5 bytes per component in HBM instead of 4. Same query API and results type as
     SeismicIndex; scores differ by the 8-bit quantisation of the document values. u16 components only, as
     in the reference. (vectorium's DotVByteFixedU8Encoder is not in the reference tree: the fixed-point

@@ -462,8 +462,9 @@ def test_cpu_quota_of_the_container_caps_the_default_host_team(tmp_path, monkeyp
 
 
 def test_dotvbyte_records_decode_to_their_documents(tmp_path):
-    """SGPU_VAL_DOTVBYTE: every record the product packs (eight 12-bit component gaps per slice, raw fallback for a
-    document with a first component or a gap >= 4096) decodes - by the oracle's independent restatement of the layout -
+    """SGPU_VAL_DOTVBYTE: every record the product packs (per 8-element slice the first component in 16 bits, three
+    12-bit and four 11-bit gaps; raw fallback for a document with a gap that does not fit its field) decodes - by the
+    oracle's independent restatement of the layout -
     to the document it was packed from; padding elements leave component and score alone; the conversions and the
     index file keep codes and components; what the format refuses is refused loudly."""
     rng = np.random.default_rng(11)
@@ -479,10 +480,13 @@ def test_dotvbyte_records_decode_to_their_documents(tmp_path):
         if d % 50 == 3 and n > 1:
             c = np.sort(np.unique(np.concatenate([c[:-1], [dim - 1]]))).astype(np.uint32)   # a last gap that may be wide
         vecs.append((c, (rng.exponential(0.5, len(c)) + 0.01).astype(np.float32)))
-    # exactly at the limits of a 12-bit gap: first component 4095 (fits) and 4096 (raw), gap 4095 / 4096
-    vecs.append((np.array([4095, 4095 + 4095], np.uint32), np.array([1.0, 2.0], np.float32)))
-    vecs.append((np.array([4096, 4097], np.uint32), np.array([1.0, 2.0], np.float32)))
+    # exactly at the limits of the fields: a 12-bit gap (elements 1 .. 3 of a slice) of 4095 fits, 4096 does not; an
+    # 11-bit gap (elements 4 .. 7) of 2047 fits, 2048 does not; a slice's first component is absolute (any u16 value)
+    vecs.append((np.array([50000, 50000 + 4095], np.uint32), np.array([1.0, 2.0], np.float32)))
     vecs.append((np.array([10, 10 + 4096], np.uint32), np.array([1.0, 2.0], np.float32)))
+    vecs.append((np.array([0, 1, 2, 3, 3 + 2047], np.uint32), np.arange(1, 6).astype(np.float32)))
+    vecs.append((np.array([0, 1, 2, 3, 3 + 2048], np.uint32), np.arange(1, 6).astype(np.float32)))
+    vecs.append((np.array([0, 1, 2, 3, 4, 5, 6, 7, 7 + 50000, 7 + 50001], np.uint32), np.arange(1, 11).astype(np.float32)))   # a new slice: any jump
     off, comps, vals = orc.csr(vecs)
     f16 = _native.NativeIndex.build(2, dim, off, comps, vals, BuildConfig.defaults(n_postings=50))
     dvb = f16.convert(2)
@@ -511,7 +515,9 @@ def test_dotvbyte_records_decode_to_their_documents(tmp_path):
         s, e = int(fo[doc]), int(fo[doc + 1])
         assert ln == e - s
         c_doc = a2["fwd_comps"][s:e].astype(np.int64)
-        wide = ln > 0 and (int(c_doc[0]) >= 4096 or (ln > 1 and int(np.diff(c_doc).max()) >= 4096))
+        gaps = np.diff(c_doc)                     # gaps[i - 1] = gap of element i; elements 8s are stored absolutely
+        pos = np.arange(1, ln) & 7
+        wide = ln > 1 and bool(np.any((pos != 0) & (gaps >= np.where(pos <= 3, 4096, 2048))))
         assert bool(raw) == wide, (doc, raw, c_doc[:4])
         n_raw += raw
         co, vo = np.zeros(max(ln, 1), np.uint16), np.zeros(max(ln, 1), np.uint8)

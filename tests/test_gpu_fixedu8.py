@@ -147,7 +147,7 @@ def test_fixed_u8_values_with_u32_components():
 def _gappy_dataset(seed, n_docs, dim):
     """Documents that exercise every record form of the DotVByte layout: lengths 0, 1, 7, 8, 9, 127 ... 300 (one, two
     and more passes of the 16-lane groups), vocabularies wide enough that some documents have a first component or a
-    gap >= 4096 (raw fallback) and some do not."""
+    gap too wide for its field (raw fallback) and some do not."""
     rng = np.random.default_rng(seed)
     lens = [0, 1, 7, 8, 9, 16, 120, 127, 128, 129, 255, 256, 257, 300, 390]
     vecs = []
@@ -165,7 +165,7 @@ def _gappy_dataset(seed, n_docs, dim):
                                  dict(SGPU_FWD_LAYOUT="doc"), dict(SGPU_COOP="force", SGPU_COOP_MIN_ITEMS="0"),
                                  dict(SGPU_ITEMS_MAX="64", SGPU_ITEMS_INIT="16", SGPU_ITEMS_MIN="16", SGPU_RBLOCKS="1")])
 def test_dotvbyte_component_stream_is_lossless_on_the_gpu(env, monkeypatch):
-    """SGPU_VAL_DOTVBYTE (fixed-u8 values + eight 12-bit component gaps per slice, raw fallback per document): the
+    """SGPU_VAL_DOTVBYTE (fixed-u8 values + per slice a 16-bit first component, three 12-bit and four 11-bit gaps; raw fallback per document): the
     codec is lossless, so every search returns the fixed-u8 index's rows bit for bit - and the oracle's."""
     for k_, v_ in env.items():
         monkeypatch.setenv(k_, v_)
