@@ -960,9 +960,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
                         !env_u32("SGPU_NO_DENSE", 0) && searching;
   const uint64_t split_bits = up((uint64_t)words * 4), split_bytes = split_bits + up((uint64_t)words * 2);
   // the round's item tables shrink (down to 256 items) if that is what keeps 2 workgroups per CU
-  // (a DotVByte index: + the round's list of raw-form items, ChunkBufs::it_raw)
-  const uint64_t raw_list = d->value_type == SGPU_VAL_DOTVBYTE ? 2u : 0u;
-  auto uni_for = [&](uint32_t items) { return up(std::max<uint64_t>((uint64_t)items * (16 + raw_list) + NT * 12, sort_bytes)); };
+  auto uni_for = [&](uint32_t items) { return up(std::max<uint64_t>((uint64_t)items * 16 + NT * 12, sort_bytes)); };
   const uint64_t smallest_lookup = (d->comp_width == 4) ? split_bytes : bitmap_bytes;
   const uint32_t want_items = items_max;
   if (!env_get("SGPU_ITEMS_MAX")) {
