@@ -1103,6 +1103,10 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   {
     const bool force = a->coop.enabled == 2;
     const uint64_t uni_bytes = a->lds_bytes - a->L.uni;
+    if (a->coop.enabled && !force) {   // (experiment knob: fewer resident workgroups for latency-bound launches)
+      const uint32_t cg = env_u32("SGPU_COOP_GRID", 0);
+      if (cg) grid = std::max<uint32_t>(std::min<uint32_t>(grid, cg), std::min<uint32_t>(b->nq, grid));
+    }
     if (a->coop.enabled && grid > 512) {   // the open-round bitmap has 512 bits: the cooperative grid is capped there
       if (env_u32("SGPU_DEBUG", 0)) std::fprintf(stderr, "sgpu coop: grid %u capped at 512 (board size)\n", grid);
       grid = 512;
