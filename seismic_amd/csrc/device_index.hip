@@ -1103,8 +1103,16 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   {
     const bool force = a->coop.enabled == 2;
     const uint64_t uni_bytes = a->lds_bytes - a->L.uni;
-    if (a->coop.enabled && !force) {   // (experiment knob: fewer resident workgroups for latency-bound launches)
-      const uint32_t cg = env_u32("SGPU_COOP_GRID", 0);
+    if (a->coop.enabled && !force) {
+      // How many workgroups a latency-bound launch keeps resident (r04, measured at three operating points of the 8.8M-
+      // document collection, profiles/r04_coop_grid.txt): every slot of the chip is too many for one or two queries -
+      // 256 helpers attach, load the query, claim from one word and have to leave again before the launch ends: a single
+      // query takes 147.6 us with 256 workgroups, 129.0 with 64 - 96 and 129.6 with 48 (the 0.95 / 0.99-recall indexes:
+      // 256 -> 228, 361 -> 326 us); two queries are best served by 96 - 128 (157 -> 146 us), eight by 128 - 256 (+-1 %),
+      // 32 and more by all of them. Rule: 48 + 32 per query, scaled to the chip's CU count. SGPU_COOP_GRID overrides.
+      const uint32_t rule = (uint32_t)(((uint64_t)48 + 32ull * b->nq) * d->n_cu / 256);
+      uint32_t cg = env_u32("SGPU_COOP_GRID", 0xffffffffu);   // unset: the rule; 0: every slot; n: at most n workgroups
+      if (cg == 0xffffffffu) cg = std::max<uint32_t>(rule, 8);
       if (cg) grid = std::max<uint32_t>(std::min<uint32_t>(grid, cg), std::min<uint32_t>(b->nq, grid));
     }
     if (a->coop.enabled && grid > 512) {   // the open-round bitmap has 512 bits: the cooperative grid is capped there
