@@ -65,6 +65,9 @@ void batch_free(sgpu_batch* b);
 struct Lane {
   hipStream_t stream = nullptr;
   uint32_t* queue = nullptr;       // the launch's work counter (queries are pulled from it)
+  // latency-bound calls (direct-in): a second counter (queue + 16) that is never reset - the host knows its value
+  uint32_t queue_pos = 0;          //   ... after everything enqueued so far
+  bool queue_dirty = true;         //   ... unless a launch failed (or none ran yet): zero it first
   sgpu_batch* scratch = nullptr;   // pool lanes: the recycled device batch (no allocation per call)
   uint32_t* bitmaps = nullptr;     // visited bitmaps of the counted pass, one per resident workgroup
   uint32_t bitmaps_slots = 0;
@@ -509,6 +512,8 @@ struct sgpu_batch {
   uint8_t* arena_host = nullptr;
   uint8_t* arena_host_dev = nullptr;   // the pinned host arena as the device sees it (small calls write their rows straight into it)
   bool direct_out = false;
+  bool direct_in = false;              // the kernel reads the queries from the pinned host arena (no H2D copy to enqueue)
+  uint32_t queue_base = 0;             // KParams::queue_base of the next launch
   size_t arena_cap = 0, in_bytes = 0, out_off = 0, out_bytes = 0;
   uint32_t* queue_dev = nullptr;
 };
@@ -1034,6 +1039,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->p.rblocks_max = std::min<uint32_t>(32, std::max<uint32_t>(1, env_u32("SGPU_RBLOCKS", 8)));   // one mask bit per block
   a->p.target_list = mode == MODE_DOTS ? sp.query_cut : 0;
   a->p.val_scale = d->val_scale;
+  a->p.queue_base = b->staged ? b->queue_base : 0u;
   a->value_type = d->value_type;
   a->ix = d->view;
   a->comp_width = d->comp_width;
@@ -1419,17 +1425,24 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   }
   std::memcpy(hs + o_order, b->plans.back().order.data(), (size_t)nq * 8);
   std::memset(hs + o_status, 0, 16);
-  b->queue_dev = (uint32_t*)b->arena_dev;
-  b->q_off = (uint32_t*)(b->arena_dev + o_off);
-  b->q_comp = (uint32_t*)(b->arena_dev + o_comp);
-  b->q_val = (float*)(b->arena_dev + o_val);
-  b->q_order = (uint32_t*)(b->arena_dev + o_order);
-  b->order_cut = cut;
   // A latency-bound call (a handful of queries) has the kernel write its few result rows straight into the pinned
   // host arena (mapped, fine-grained: posted writes over PCIe, visible once the stream is done): no D2H copy to
-  // enqueue, none to wait for. Larger calls keep the device-side slab and one D2H.
+  // enqueue, none to wait for. Larger calls keep the device-side slab and one D2H. Since r04 such a call also lets the
+  // kernel READ its queries (a few hundred bytes) from that arena: no H2D copy to enqueue (5 us of host time and a
+  // copy command ahead of the kernel) - which leaves the work counter: it is not zeroed per launch but runs on
+  // (KParams::queue_base; Lane::queue_pos mirrors it on the host).
   static const uint32_t direct_max = env_u32("SGPU_DIRECT_OUT_MAX", 16);
+  static const uint32_t direct_in_on = env_u32("SGPU_DIRECT_IN", 1);
   b->direct_out = b->arena_host_dev != nullptr && nq <= direct_max;
+  b->direct_in = b->direct_out && direct_in_on != 0;
+  uint8_t* in_base = b->direct_in ? b->arena_host_dev : b->arena_dev;
+  b->queue_dev = b->direct_in ? lane->queue + 16 : (uint32_t*)b->arena_dev;
+  b->queue_base = 0;
+  b->q_off = (uint32_t*)(in_base + o_off);
+  b->q_comp = (uint32_t*)(in_base + o_comp);
+  b->q_val = (float*)(in_base + o_val);
+  b->q_order = (uint32_t*)(in_base + o_order);
+  b->order_cut = cut;
   uint8_t* out_base = b->direct_out ? b->arena_host_dev : b->arena_dev;
   b->out_n = (uint32_t*)(out_base + r_n);
   b->out_scores = (float*)(out_base + r_sc);
@@ -1437,7 +1450,16 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   b->out_stats = nullptr;
   b->status = (uint32_t*)(out_base + o_status);
   pc.lap(1);
-  HIP_TRY(hipMemcpyAsync(b->arena_dev, hs, in_bytes, hipMemcpyHostToDevice, lane->stream));
+  if (b->direct_in) {
+    if (lane->queue_dirty) {   // first use of the lane, or a launch on it failed: the counter's value is not known
+      HIP_TRY(hipMemsetAsync(lane->queue + 16, 0, 4, lane->stream));
+      lane->queue_pos = 0;
+      lane->queue_dirty = false;
+    }
+    b->queue_base = lane->queue_pos;
+  } else {
+    HIP_TRY(hipMemcpyAsync(b->arena_dev, hs, in_bytes, hipMemcpyHostToDevice, lane->stream));
+  }
   pc.lap(2);
   // from here on a failure waits for the stream: the lane (and its pinned arena) goes back to the pool
   hipError_t he = hipSuccess;
@@ -1446,6 +1468,10 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     LaunchArgs a{};
     st = configure(d, lane, b, sp, MODE_SEARCH, &a);
     if (st == SGPU_OK) he = launch_search(a);
+    if (b->direct_in) {
+      if (st == SGPU_OK && he == hipSuccess) lane->queue_pos += nq + a.grid;   // the tickets this launch takes
+      else lane->queue_dirty = true;
+    }
   }
   pc.lap(3);
   if (st == SGPU_OK && he == hipSuccess && !b->direct_out)
@@ -1463,12 +1489,19 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
 sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_scores, uint64_t* out_ids, uint32_t* out_n) {
   HIP_TRY(hipSetDevice(d->device));
   PhaseClock pc;
-  HIP_TRY(wait_lane(lane->stream, b ? b->nq : 0));
+  {
+    const hipError_t we = wait_lane(lane->stream, b ? b->nq : 0);
+    if (we != hipSuccess) lane->queue_dirty = true;   // (the running work counter of direct-in calls is no longer known)
+    HIP_TRY(we);
+  }
   pc.lap(5);
   if (!b || b->nq == 0) return SGPU_OK;
   if (lane->coop_last) {   // the launch's status word came back with the rows
     const sgpu_status cs = coop_report(d, lane, *(const volatile uint32_t*)(b->arena_host + b->status_off));
-    if (cs != SGPU_OK) return cs;
+    if (cs != SGPU_OK) {
+      lane->queue_dirty = true;
+      return cs;
+    }
   }
   const size_t nq = b->nq, k = b->k_max;
   const uint8_t* r = b->arena_host + b->out_off;

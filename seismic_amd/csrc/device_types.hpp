@@ -126,6 +126,9 @@ struct KParams {
   uint32_t n_knn;        // neighbours of each result to rescore after the lists (Knn::refine); 0 = off
   uint32_t target_list;  // MODE_DOTS: the posting list whose summary dots are wanted
   float val_scale;       // fixed-u8 document values: value = code * val_scale (a power of two)
+  uint32_t queue_base;   // value of the work counter when the launch starts (0 when the counter is zeroed per launch;
+                         // latency-bound calls let it run on: a launch of nq queries on a grid of G workgroups takes
+                         // exactly nq + G tickets, so the host knows where the next launch begins - no reset to enqueue)
 };
 
 // The scoring loop's weights (q_sc, preceded by the 0.0 slot) sit at a FIXED offset of the dynamic LDS, so that the
