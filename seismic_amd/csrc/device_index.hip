@@ -68,6 +68,7 @@ struct Lane {
   // latency-bound calls (direct-in): a second counter (queue + 16) that is never reset - the host knows its value
   uint32_t queue_pos = 0;          //   ... after everything enqueued so far
   bool queue_dirty = true;         //   ... unless a launch failed (or none ran yet): zero it first
+  uint32_t done_seq = 0;           // BatchView::done_seq of the lane's last early-done launch
   sgpu_batch* scratch = nullptr;   // pool lanes: the recycled device batch (no allocation per call)
   uint32_t* bitmaps = nullptr;     // visited bitmaps of the counted pass, one per resident workgroup
   uint32_t bitmaps_slots = 0;
@@ -512,6 +513,7 @@ struct sgpu_batch {
   uint8_t* arena_host = nullptr;
   uint8_t* arena_host_dev = nullptr;   // the pinned host arena as the device sees it (small calls write their rows straight into it)
   bool direct_out = false;
+  uint32_t done_seq = 0;               // direct-out calls: the value the launch's last query stores into the arena's done word (0: none)
   bool direct_in = false;              // the kernel reads the queries from the pinned host arena (no H2D copy to enqueue)
   uint32_t queue_base = 0;             // KParams::queue_base of the next launch
   size_t arena_cap = 0, in_bytes = 0, out_off = 0, out_bytes = 0;
@@ -588,7 +590,9 @@ struct PhaseClock {
 // 192 us outside the kernel on the driver's box against 17 us on a busy one). A call small enough to be
 // latency-bound polls the stream instead (hipStreamQuery, no system call once the signal is mapped)
 // for at most SGPU_SPIN_US microseconds (default 2000) and only then parks. SGPU_WAIT=block|spin overrides.
-static hipError_t wait_lane(hipStream_t s, uint32_t nq) {
+// (done / done_seq: the launch stores done_seq into *done - pinned host memory - once every result row is there: the
+// wait ends then, whether or not the launch itself has ended)
+static hipError_t wait_lane(hipStream_t s, uint32_t nq, const volatile uint32_t* done = nullptr, uint32_t done_seq = 0) {
   static const int mode = [] {
     const char* v = std::getenv("SGPU_WAIT");
     return (v && !std::strcmp(v, "block")) ? 0 : ((v && !std::strcmp(v, "spin")) ? 2 : 1);
@@ -597,6 +601,7 @@ static hipError_t wait_lane(hipStream_t s, uint32_t nq) {
   if (mode == 2 || (mode == 1 && nq <= 256)) {
     const double t0 = now_us();
     for (;;) {
+      if (done && __atomic_load_n((const uint32_t*)done, __ATOMIC_ACQUIRE) == done_seq) return hipSuccess;
       const hipError_t e = hipStreamQuery(s);
       if (e == hipSuccess) return hipSuccess;
       if (e != hipErrorNotReady) return e;
@@ -1072,6 +1077,8 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   }
   a->qb.out_stats = mode != MODE_DOTS ? b->out_stats : nullptr;   // (null for staged batches: no work counters)
   a->qb.status = b->staged ? b->status : nullptr;
+  a->qb.done = nullptr;   // (set below for cooperative launches that write their rows to the host arena)
+  a->qb.done_seq = 0;
   // cooperative variant wanted? (decided before the occupancy query: it is its own kernel symbol)
   a->coop = CoopView{};
   {
@@ -1178,6 +1185,16 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     a->p.items_init = std::min<uint32_t>(a->p.items_max, std::max<uint32_t>(1, env_u32("SGPU_COOP_ITEMS_INIT", 128)));
   if (!a->coop.enabled) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
   a->grid = grid;
+  // A cooperative launch that writes its rows straight into the pinned host arena also tells the host when the LAST
+  // query's rows are there (BatchView::done): the call returns them while the launch winds down (helpers leaving, the
+  // board being cleared), and the next call's launch queues up behind it (r04; SGPU_EARLY_DONE=0: wait for the launch).
+  b->done_seq = 0;
+  if (a->coop.enabled && b->staged && b->direct_out && b->status && env_u32("SGPU_EARLY_DONE", 1)) {
+    lane->done_seq = lane->done_seq == 0xffffffffu ? 1u : lane->done_seq + 1u;
+    b->done_seq = lane->done_seq;
+    a->qb.done = b->status + 1;
+    a->qb.done_seq = b->done_seq;
+  }
   // visited bitmaps: one per resident workgroup (counted pass)
   a->bitmaps = nullptr;
   if (a->counted) {
@@ -1490,7 +1507,8 @@ sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_
   HIP_TRY(hipSetDevice(d->device));
   PhaseClock pc;
   {
-    const hipError_t we = wait_lane(lane->stream, b ? b->nq : 0);
+    const volatile uint32_t* done = (b && b->done_seq) ? (const volatile uint32_t*)(b->arena_host + b->status_off + 4) : nullptr;
+    const hipError_t we = wait_lane(lane->stream, b ? b->nq : 0, done, b ? b->done_seq : 0u);
     if (we != hipSuccess) lane->queue_dirty = true;   // (the running work counter of direct-in calls is no longer known)
     HIP_TRY(we);
   }

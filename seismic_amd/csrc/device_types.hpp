@@ -47,6 +47,9 @@ struct BatchView {
   uint32_t* out_stats;     // optional nq x STATS_WORDS counters (zeroed by the host before a pass)
   uint32_t* status;        // optional launch status word (zero before the launch; the cooperative variant stores a
                            //   protocol-error code here - it comes back to the host with the result rows)
+  uint32_t* done;          // optional (cooperative launches whose rows go straight to the pinned host arena): the workgroup
+  uint32_t done_seq;       //   that finishes the LAST query stores done_seq here, at system scope, after every row has
+                           //   left its writer - the host may hand the rows out while the launch winds down
 };
 
 enum { MODE_SEARCH = 0, MODE_DOTS = 1, MODE_COUNTED = 2 };   // COUNTED: search with the visited bitmap (exact counters)

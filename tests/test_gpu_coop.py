@@ -83,3 +83,35 @@ def test_cooperative_launches_keep_the_board_clean(monkeypatch):
         o0, o1 = int(q_off[lo]), int(q_off[lo + nq])
         got = ix.batch_search(q_off[lo:lo + nq + 1] - q_off[lo], qc[o0:o1], qv[o0:o1], 10, 4, 1.0, False)
         assert _same(got, tuple(x[lo:lo + nq] for x in want)), (it, nq, lo)
+
+
+@pytest.mark.parametrize("mode", ["auto", "force"])
+def test_rows_are_complete_when_a_small_call_returns_early(mode, monkeypatch):
+    """A cooperative call of at most 16 queries returns as soon as the launch's LAST query has stored the done word
+    into the pinned host arena - the launch is still winding down then (r04). Every row of every query of the call
+    must be there: the rows of a query and the done word can leave from different XCDs, so each workgroup releases its
+    rows at system scope before its query counts as finished (a mere drain lost rows of earlier queries). Many calls of
+    2 .. 16 queries back to back, each compared with the rows of one large launch; then the same with the early
+    return switched off."""
+    if mode == "force":
+        monkeypatch.setenv("SGPU_COOP", "force")
+    ix, q = _shape(300_000, 600, 1200)
+    off, qc, qv = q
+    want = ix.batch_search(off, qc, qv, 10, 4, 1.0, False)   # one plain launch of 1200 queries
+
+    def call(a, b):
+        o = (off[a:b + 1] - off[a]).astype(np.uint64)
+        return ix.batch_search(o, qc[int(off[a]):int(off[b])], qv[int(off[a]):int(off[b])], 10, 4, 1.0, False)
+
+    for early in ("1", "0"):
+        monkeypatch.setenv("SGPU_EARLY_DONE", early)
+        a = 0
+        for it in range(150):
+            n = (2, 5, 15, 16, 3, 1, 9)[it % 7]
+            if a + n > 1200:
+                a = 0
+            gs, gi, gn = call(a, a + n)
+            assert np.array_equal(gn, want[2][a:a + n]), (early, it, n, gn, want[2][a:a + n])
+            assert np.array_equal(gi, want[1][a:a + n]), (early, it, n)
+            assert np.array_equal(gs.view(np.uint32), want[0][a:a + n].view(np.uint32)), (early, it, n)
+            a += n
