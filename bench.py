@@ -78,6 +78,9 @@ def parse_args():
                          "component stream - the forward index of the reference's DotVByte index)")
     ap.add_argument("--sample", type=int, default=1000,
                     help="queries of the first timed batch used for recall, the oracle identity check and cpu_baseline")
+    ap.add_argument("--heldout", type=int, default=4000,
+                    help="queries of the same batch, disjoint from --sample, on which every operating point's recall is "
+                         "REPORTED (its parameters are selected on the sample only)")
     ap.add_argument("--build-on-host", action="store_true",
                     help="build the index on the host cores only (default: the clustering step runs on the GPU; "
                          "the index is byte-identical either way)")
@@ -203,6 +206,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    if local_world > 1 and "SGPU_HOST_THREADS" not in os.environ:
+        # the ranks of a node share its host cores (and the container's CPU quota): each takes its share for the
+        # host-parallel phases (index build, packing at upload, exact search) instead of a full team per rank
+        quota_ = cpu_quota()
+        cores_ = os.cpu_count() or 1
+        team_ = cores_ if quota_ is None else max(1, min(cores_, int(quota_)))
+        os.environ["SGPU_HOST_THREADS"] = str(max(1, team_ // local_world))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                          % (args.gpus, args.gpus))
@@ -367,6 +378,20 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         entry_results = {bi: tuple(a.copy() for a in outs[bi]) for bi in timed_ids[:1]}
+    # N > 1, BASELINE configs[3] read literally: ONE batch at a time - a barrier before and after every step, each rank
+    # issues its shard as one call from one thread, so no call of a later batch hides a rank's host side or fills its
+    # launch tail. Reported NEXT to `value` (whose K calls are issued back to back from the request threads).
+    one_at_a_time = None
+    if world > 1 and scaling == "strong" and not args.no_entry:
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            entry_call(args.warmup + i)()
+            barrier()
+        dt1 = time.perf_counter() - t0
+        t = torch.tensor([dt1], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        one_at_a_time = float(t.item())
 
     # ---------------- kernel leg (roofline): the same batches resident in HBM, HIP events around each launch ----------------
     def step(i):
@@ -499,6 +524,16 @@ def main():
         },
         "timing_s": {"generate": t_gen, "build": t_build, "upload": t_up},
     }
+    if world > 1:
+        out["value_is"] = ("pipelined: the K sharded batches are issued back to back from %d request thread(s) per rank, so "
+                           "calls of consecutive batches overlap on a GPU" % n_threads)
+        out["host_threads_per_rank_for_host_phases"] = os.environ.get("SGPU_HOST_THREADS")
+    if one_at_a_time is not None:
+        out["value_one_batch_at_a_time"] = args.queries * args.steps / one_at_a_time
+        out["one_batch_at_a_time"] = {
+            "value": args.queries * args.steps / one_at_a_time, "unit": "queries/s", "ms_per_step": one_at_a_time * 1e3 / args.steps,
+            "note": "a barrier around every step, each rank's shard = one sgpu_batch_search call from one thread "
+                    "(BASELINE configs[3] read literally; includes one barrier per step)"}
 
     # ---- N>1, strong scaling: the sharded batch must be the 1-GPU answer, in input order ----
     if world > 1 and scaling == "strong":
@@ -576,13 +611,20 @@ def main():
         # mean latency of batch-1 searches: the reference's AQT loop (one query at a time,
         # src/bin/perf_inverted_index.rs:184-216) natively - sgpu_search_sequential = one sgpu_search per query,
         # host buffers in and out, timed around the loop - over the whole sample, three passes
-        runs, phases = [], None
+        runs, phases, each = [], None, []
         index.search_sequential(s_off[:11], s_comp, s_val, args.k, args.query_cut, args.heap_factor, srt)
         for rep in range(3):
-            lsc, lid, ln, mean_us, ph = index.search_sequential(s_off, s_comp, s_val, args.k, args.query_cut, args.heap_factor, srt)
+            lsc, lid, ln, mean_us, ph, per_q = index.search_sequential(s_off, s_comp, s_val, args.k, args.query_cut, args.heap_factor, srt,
+                                                                       per_query=True)
             runs.append(mean_us)
+            each.append(per_q)
             phases = ph if phases is None else phases + ph
+        each = np.concatenate(each)
         out["mean_latency_us_single_query"] = float(np.mean(runs))
+        out["latency_percentiles_us_single_query"] = {
+            "p50": float(np.percentile(each, 50)), "p95": float(np.percentile(each, 95)), "p99": float(np.percentile(each, 99)),
+            "max": float(each.max()), "min": float(each.min()), "mean": float(each.mean()), "calls": int(len(each)),
+            "note": "wall time of every sgpu_search call of the three passes (sgpu_search_sequential_timed)"}
         out["latency"] = {
             "entry_point": "sgpu_search, one call per query, sequential (sgpu_search_sequential)",
             "queries": ns, "passes_mean_us": runs,
@@ -618,13 +660,22 @@ def main():
     exact_ids = None
     if rank == 0 and not args.no_recall:
         t0 = time.time()
-        es, ei, en = index.exact_search(s_off, s_comp, s_val, args.k)
-        exact_ids = [set(ei[i, :en[i]].tolist()) for i in range(ns)]
+        # exact top-k (host, all documents) of the sample AND of the held-out queries [ns, ns + nh) of the same batch:
+        # parameters of the operating points are selected on the sample, their recall is reported on the held-out queries
+        nh = max(0, min(args.heldout, my_q - ns)) if (world == 1 and args.target_recall.strip()) else 0
+        x_off, x_comp, x_val = host_batches[first]
+        x_off = x_off[:ns + nh + 1].copy()
+        es, ei, en = index.exact_search(x_off, x_comp[:int(x_off[ns + nh])], x_val[:int(x_off[ns + nh])], args.k)
+        exact_ids = [set(ei[i, :en[i]].tolist()) for i in range(ns + nh)]
 
-        def recall_of(ids, n):
-            return sum(len(set(ids[i, :n[i]].tolist()) & exact_ids[i]) for i in range(ns)) / float(max(ns, 1) * args.k)
+        def recall_of(ids, n, lo=0, hi=None):
+            hi = ns if hi is None else hi
+            return sum(len(set(ids[i, :n[i]].tolist()) & exact_ids[i]) for i in range(lo, hi)) / float(max(hi - lo, 1) * args.k)
         out["recall_at_k"] = recall_of(gid, gn)
         out["recall_sample_queries"] = ns
+        if nh:
+            out["recall_heldout"] = recall_of(gid, gn, ns, ns + nh)
+            out["recall_heldout_queries"] = nh
         out["timing_s"]["exact_ground_truth"] = time.time() - t0
 
     if rank == 0 and world == 1 and exact_ids is not None and args.target_recall.strip():
@@ -688,11 +739,11 @@ def main():
 
             def measure(ix_, bs_, cut, hf, fs):
                 """One (query_cut, heap_factor, first_sorted) on resident batch 0 of bs_ (it holds the sample): kernel ms of the
-                whole-batch launch (best of two) and recall@k of the sample rows."""
+                whole-batch launch (best of two), recall@k of the sample rows (selection) and of the held-out rows (report)."""
                 bs_[0].run(args.k, cut, hf, fs)
                 ms_ = min(bs_[0].run(args.k, cut, hf, fs).kernel_ms for _ in range(2))
                 _, pid_, pn_ = bs_[0].fetch(args.k)
-                return float(ms_), recall_of(pid_, pn_)
+                return float(ms_), recall_of(pid_, pn_), (recall_of(pid_, pn_, ns, ns + nh) if nh else None)
 
             # the recorded points belong to the collection they were swept on
             rec_applies = (not args.documents and recorded.get("docs") == args.docs and recorded.get("dim") == args.dim
@@ -728,12 +779,20 @@ def main():
                     mkey = (json.dumps(ip, sort_keys=True), cut, hf, fs)
                     if mkey not in measured:
                         measured[mkey] = measure(ix_, bs_, cut, hf, fs)
-                    ms_, rc_ = measured[mkey]
-                    tried.append({"query_cut": cut, "heap_factor": hf, "first_sorted": fs, "recall": rc_, "batch_kernel_ms": ms_})
-                ok = [g for g in tried if g["recall"] >= tgt]
+                    ms_, rc_, rh_ = measured[mkey]
+                    tried.append({"query_cut": cut, "heap_factor": hf, "first_sorted": fs, "recall": rc_, "recall_heldout": rh_,
+                                  "batch_kernel_ms": ms_})
+                # SELECTION looks at the sample only (queries 0 .. ns-1): the cheapest candidate whose sample recall clears
+                # the target by a margin of two standard errors of a recall measured on ns x k slots (the sample estimate of
+                # a point that sits exactly on the target is below it half of the time); without such a candidate, the
+                # cheapest one that reaches the target on the sample. The point's recall is then REPORTED on the held-out
+                # queries, which played no part in the choice, and it counts as reached only if that figure meets the target.
+                margin = 2.0 * (tgt * (1.0 - tgt) / float(max(ns, 1) * args.k)) ** 0.5 if nh else 0.0
+                ok = [g for g in tried if g["recall"] >= tgt + margin] or [g for g in tried if g["recall"] >= tgt]
                 if not ok:
                     best = max(tried, key=lambda g: g["recall"])
                     points.append({"target_recall": tgt, "reached": False, "index": ip, "best_recall_on_grid": best["recall"],
+                                   "best_recall_heldout": best["recall_heldout"],
                                    "at": {k_: best[k_] for k_ in ("query_cut", "heap_factor", "first_sorted")}, "tried": len(tried)})
                     continue
                 g = min(ok, key=lambda g: g["batch_kernel_ms"])
@@ -759,7 +818,12 @@ def main():
                         if rep:
                             best_n = max(best_n, ns / r_[4])
                         used_n = int(r_[5])
-                _, _, _, lat_us, _ = ix_.search_sequential(s_off[:min(ns, 300) + 1], s_comp, s_val, args.k, cut, hf, fs)
+                # single-query latency on held-out queries (the first 300 behind the sample), with its distribution
+                l0_, l1_ = (ns, min(ns + 300, ns + nh)) if nh else (0, min(ns, 300))
+                l_off = (x_off[l0_:l1_ + 1] - x_off[l0_]).astype(np.uint64)
+                l_comp, l_val = x_comp[int(x_off[l0_]):int(x_off[l1_])], x_val[int(x_off[l0_]):int(x_off[l1_])]
+                ix_.search_sequential(l_off[:11], l_comp, l_val, args.k, cut, hf, fs)
+                _, _, _, lat_us, _, lat_each = ix_.search_sequential(l_off, l_comp, l_val, args.k, cut, hf, fs, per_query=True)
                 pa = argparse.Namespace(**vars(args))
                 pa.n_postings, pa.max_fraction = int(ip["n_postings"]), float(ip["max_fraction"])
                 pa.centroid_fraction, pa.summary_energy = float(ip["centroid_fraction"]), float(ip["summary_energy"])
@@ -767,10 +831,17 @@ def main():
                 pkey = workload_key(pa, world, scaling)
                 ptraffic, pnote = recorded_traffic(pkey)
                 kms_ = float(st_.kernel_ms)
-                pt = {"target_recall": tgt, "reached": True, "index": dict(ip, hbm_bytes=ix_.device_bytes(), build_s=tb_, upload_s=tu_,
-                                                                          same_as_headline=same_index),
+                held = g["recall_heldout"]
+                pt = {"target_recall": tgt, "reached": bool((held if held is not None else g["recall"]) >= tgt),
+                      "index": dict(ip, hbm_bytes=ix_.device_bytes(), build_s=tb_, upload_s=tu_, same_as_headline=same_index),
                       "query_cut": cut, "heap_factor": hf, "first_sorted": fs,
-                      "recall_at_k": g["recall"], "value": my_q * nb_ / dt_e, "unit": "queries/s",
+                      "recall_at_k": held if held is not None else g["recall"],
+                      "recall_selection_sample": g["recall"], "recall_heldout": held,
+                      "recall_queries": {"selection": [0, ns], "heldout": [ns, ns + nh], "selection_margin": margin},
+                      "latency_percentiles_us": {"p50": float(np.percentile(lat_each, 50)), "p95": float(np.percentile(lat_each, 95)),
+                                                 "p99": float(np.percentile(lat_each, 99)), "max": float(lat_each.max()),
+                                                 "queries": [int(l0_), int(l1_)]},
+                      "value": my_q * nb_ / dt_e, "unit": "queries/s",
                       "device_resident_qps": my_q / (kms_ * 1e-3) if kms_ > 0 else None,
                       "kernel_ms": kms_, "mean_latency_us_single_query": lat_us,
                       "roofline_frac": ab / (kms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS if kms_ > 0 else None,
@@ -796,7 +867,9 @@ def main():
             out["operating_points_source"] = {
                 "file": "profiles/operating_points.json", "sweep": recorded.get("sweep"),
                 "selection": "per target the cheapest whole-batch kernel time among index AND query parameters (tools/operating_sweep.py); "
-                             "query parameters re-selected here on this run's %d-query sample among the recorded point and its neighbours" % ns}
+                             "query parameters re-selected here on this run's %d-query sample among the recorded point and its neighbours; "
+                             "recall REPORTED on %d held-out queries of the same batch (a point is `reached` only if the held-out recall "
+                             "meets its target)" % (ns, nh)}
             out["timing_s"]["operating_points"] = time.time() - t0
         except Exception as e:   # (the headline line must survive a failure of this leg: it is reported, not raised)
             import traceback

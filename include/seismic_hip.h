@@ -256,6 +256,13 @@ sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const
                                    const float* vals, uint32_t nq, const sgpu_search_params* params,
                                    float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n,
                                    double* mean_us, double* breakdown_us);
+/* Same loop; per_query_us (may be NULL) additionally receives the wall time of every call, nq doubles - the
+ * distribution (p50 / p95 / p99 / max) behind the mean that perf_inverted_index reports
+ * (src/bin/perf_inverted_index.rs:184-216 times the whole loop only). */
+sgpu_status sgpu_search_sequential_timed(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps,
+                                         const float* vals, uint32_t nq, const sgpu_search_params* params,
+                                         float* out_scores, uint64_t* out_doc_ids, uint32_t* out_n,
+                                         double* mean_us, double* breakdown_us, double* per_query_us);
 
 /* Device-resident variant (what bench.py times: inputs already in HBM when the
  * timed region starts; results stay in HBM until fetched). */
@@ -335,7 +342,8 @@ typedef struct sgpu_synth_spec {
   uint64_t dim;
   uint64_t seed;
   uint32_t kind;        /* 0 docs, 1 queries */
-  uint32_t reserved;
+  uint32_t collection;  /* 0 = the SURVEY 8(d) law (the benchmark's headline collection); 1 = "clustered": documents drawn
+                           around latent intents, queries carry their source document's weights (synth.cpp) */
 } sgpu_synth_spec;
 sgpu_status sgpu_synth_generate(const sgpu_synth_spec* spec,
                                 const uint64_t* docs_offsets, const uint32_t* docs_comps,

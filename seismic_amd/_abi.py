@@ -89,5 +89,5 @@ class SynthSpec(C.Structure):
         ("dim", C.c_uint64),
         ("seed", C.c_uint64),
         ("kind", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("collection", C.c_uint32),   # 0 = SURVEY 8(d) law, 1 = clustered (synth.cpp)
     ]

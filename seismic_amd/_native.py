@@ -61,6 +61,8 @@ def lib():
         L.sgpu_batch_search.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp, vp]
         L.sgpu_search_sequential.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp, vp,
                                              C.POINTER(C.c_double), vp]
+        L.sgpu_search_sequential_timed.argtypes = [vp, vp, vp, vp, C.c_uint32, C.POINTER(SearchParams), vp, vp, vp,
+                                                   C.POINTER(C.c_double), vp, vp]
         L.sgpu_batch_create.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.POINTER(vp)]
         L.sgpu_batch_run.argtypes = [vp, vp, C.POINTER(SearchParams), C.c_int32, C.POINTER(LaunchStats)]
         L.sgpu_batch_run_counted.argtypes = [vp, vp, C.POINTER(SearchParams), C.POINTER(LaunchStats)]
@@ -231,10 +233,11 @@ class NativeIndex:
                                       _p(ids), _p(n)))
         return sc, ids, n[:nq]
 
-    def search_sequential(self, q_off, comps, vals, k, query_cut, heap_factor, first_sorted=False, n_knn=0):
+    def search_sequential(self, q_off, comps, vals, k, query_cut, heap_factor, first_sorted=False, n_knn=0, per_query=False):
         """The reference's AQT loop (src/bin/perf_inverted_index.rs:184-216) natively: one sgpu_search per
         query, timed around the loop. Returns (scores, ids, n, mean microseconds per query, the 8-entry
-        host-side phase breakdown in microseconds per query)."""
+        host-side phase breakdown in microseconds per query); with per_query=True a sixth element, the wall
+        time of every call in microseconds."""
         q_off, comps, vals = _csr(q_off, comps, vals)
         nq = len(q_off) - 1
         sc = np.zeros((nq, max(k, 1)), np.float32)
@@ -243,6 +246,11 @@ class NativeIndex:
         mean = C.c_double(0.0)
         phases = np.zeros(8, np.float64)
         p = params(k, query_cut, heap_factor, first_sorted, n_knn)
+        if per_query:
+            each = np.zeros(max(nq, 1), np.float64)
+            check(lib().sgpu_search_sequential_timed(self.h, _p(q_off), _p(comps), _p(vals), nq, C.byref(p), _p(sc), _p(ids),
+                                                     _p(n), C.byref(mean), _p(phases), _p(each)))
+            return sc, ids, n[:nq], mean.value, phases, each[:nq]
         check(lib().sgpu_search_sequential(self.h, _p(q_off), _p(comps), _p(vals), nq, C.byref(p), _p(sc), _p(ids),
                                            _p(n), C.byref(mean), _p(phases)))
         return sc, ids, n[:nq], mean.value, phases
@@ -333,9 +341,10 @@ class DeviceBatch:
             pass
 
 
-def synth(n_vecs, dim, seed, kind=0, docs=None):
-    """SPLADE-shaped synthetic CSR (offsets u64, comps u32, vals f32). kind 0 docs, 1 queries."""
-    spec = SynthSpec(n_vecs=n_vecs, dim=dim, seed=seed, kind=kind)
+def synth(n_vecs, dim, seed, kind=0, docs=None, collection=0):
+    """SPLADE-shaped synthetic CSR (offsets u64, comps u32, vals f32). kind 0 docs, 1 queries; collection 0 = the
+    SURVEY 8(d) law, 1 = clustered (documents around latent intents; pass the same value for documents and queries)."""
+    spec = SynthSpec(n_vecs=n_vecs, dim=dim, seed=seed, kind=kind, collection=collection)
     nnz = C.c_uint64(0)
     d_off = d_c = d_v = None
     nd = 0

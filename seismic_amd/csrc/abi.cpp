@@ -343,7 +343,8 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
   uint32_t tail = 0;
   uint32_t n_jobs;
   {
-    const char* tv = std::getenv("SGPU_TAIL_COOP");
+    const char* th = std::getenv("SGPU_TEST_HOOKS");   // (a test hook: honoured only while SGPU_TEST_HOOKS=1 is set)
+    const char* tv = (th && *th && *th != '0') ? std::getenv("SGPU_TAIL_COOP") : nullptr;
     const uint32_t want = tv && *tv ? (uint32_t)std::strtoul(tv, nullptr, 10) : 0u;
     n_jobs = chunk_jobs(nq, chunk_min, chunk_max, want, want ? coop_auto_max_queries(d) : 0u, &tail);
   }
@@ -475,9 +476,10 @@ sgpu_status sgpu_search(sgpu_index* idx, const uint32_t* comps, const float* val
 
 // The reference's AQT loop (src/bin/perf_inverted_index.rs:184-216): the queries of a set searched one
 // at a time, each through sgpu_search, timed around the whole loop.
-sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals,
-                                   uint32_t nq, const sgpu_search_params* params, float* out_scores,
-                                   uint64_t* out_doc_ids, uint32_t* out_n, double* mean_us, double* breakdown_us) {
+sgpu_status sgpu_search_sequential_timed(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals,
+                                         uint32_t nq, const sgpu_search_params* params, float* out_scores,
+                                         uint64_t* out_doc_ids, uint32_t* out_n, double* mean_us, double* breakdown_us,
+                                         double* per_query_us) {
   if (!idx || !params || !q_off || !out_scores || !out_doc_ids || !out_n) return fail(SGPU_EINVAL, "null argument");
   if (params->k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
   double phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -492,9 +494,11 @@ sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const
       st = fail(SGPU_EINVAL, "query offsets must be monotone (query %u)", q);
       break;
     }
+    const auto tq = per_query_us ? std::chrono::steady_clock::now() : t0;
     st = sgpu_search(idx, comps ? comps + q_off[q] : nullptr, vals ? vals + q_off[q] : nullptr,
                      (uint32_t)(q_off[q + 1] - q_off[q]), params, out_scores + (size_t)q * k,
                      out_doc_ids + (size_t)q * k, out_n + q);
+    if (per_query_us) per_query_us[q] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq).count();
   }
   const double total = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   slot = saved;
@@ -502,6 +506,13 @@ sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const
   if (breakdown_us)
     for (int i = 0; i < 8; ++i) breakdown_us[i] = nq ? phases[i] / nq : 0.0;
   return st;
+}
+
+sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals,
+                                   uint32_t nq, const sgpu_search_params* params, float* out_scores,
+                                   uint64_t* out_doc_ids, uint32_t* out_n, double* mean_us, double* breakdown_us) {
+  return sgpu_search_sequential_timed(idx, q_off, comps, vals, nq, params, out_scores, out_doc_ids, out_n, mean_us,
+                                      breakdown_us, nullptr);
 }
 
 // (not part of the boundary: the team size a host-parallel phase would take for num_threads == 0)
@@ -527,7 +538,10 @@ sgpu_status sgpu_debug_pack_forward(const sgpu_index* idx, uint8_t* out_fwd, uin
   try {
     std::vector<uint8_t> raw, fwd;
     std::vector<uint64_t> off16, dref;
-    pack_dvb_raw_flags(idx->host, &raw);
+    {   // (an f16 index: the layout sgpu_index_upload would choose - sliced unless SGPU_FWD_STREAM=plain)
+      const char* fs = std::getenv("SGPU_FWD_STREAM");
+      pack_dvb_raw_flags(idx->host, !(fs && std::string(fs) == "plain"), &raw);
+    }
     pack_record_offsets(idx->host, raw, 128 / 16, &off16);
     *out_bytes = std::max<uint64_t>(off16[idx->host.n_docs] * 16, 16);
     if (!out_fwd) return SGPU_OK;

@@ -247,8 +247,18 @@ struct DevBuf {
 };
 }  // namespace
 
-// Largest number of centroids a list may have to be clustered on the device (others stay on the host).
-uint32_t device_assign_max_centroids() { return kAssignMaxCentroids; }
+// Largest number of centroids a list may have to be clustered on the device (others stay on the host): the kernel keeps
+// one f32 accumulator per centroid and wavefront in dynamic LDS next to its static words, so the figure follows from the
+// LDS a workgroup may have on THIS device (gfx950: 160 KB -> the full 8192; a 64 KB part: 3968). 0 = no usable device -
+// device_assign_clusters then reports it.
+uint32_t device_assign_max_centroids(int device) {
+  int lds = 0;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || lds <= 0) return 0;
+  const size_t fixed = kAssignMaxCentroids / 32 * 4 + 256;   // s_avoid, s_list, alignment
+  if ((size_t)lds <= fixed) return 0;
+  const size_t fit = ((size_t)lds - fixed) / ((size_t)(kAssignThreads / 64) * 4);
+  return (uint32_t)std::min<size_t>(kAssignMaxCentroids, fit);
+}
 
 // cid_out[lp_off[c] + t] = index (within list c's centroids) of the centroid posting t of list c belongs to,
 // for every list with eligible[c] != 0. `top` holds doc_cut {component | ~0, f32 bits} pairs per document.
@@ -273,7 +283,8 @@ sgpu_status device_assign_clusters(int device, uint32_t comp_width, uint64_t n_d
       max_nc = std::max<uint32_t>(max_nc, (uint32_t)(lc_off[c + 1] - lc_off[c]));
     }
   if (order.empty()) return SGPU_OK;
-  if (max_nc > kAssignMaxCentroids) return fail(SGPU_EINVAL, "a list with %u centroids was marked for the device", max_nc);
+  if (max_nc > device_assign_max_centroids(device))
+    return fail(SGPU_EINVAL, "a list with %u centroids was marked for the device (it takes %u)", max_nc, device_assign_max_centroids(device));
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return lp_off[a + 1] - lp_off[a] > lp_off[b + 1] - lp_off[b]; });
   const size_t lds = (size_t)(kAssignThreads / 64) * max_nc * 4;
   HIP_TRY(hipFuncSetAttribute((const void*)assign_clusters_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

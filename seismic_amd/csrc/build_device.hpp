@@ -9,8 +9,9 @@
 namespace sgpu {
 
 // ---- clustering (build_assign.hip) -------------------------------------------------------------
-// Largest number of centroids a list may have to be clustered on the device (others stay on the host).
-uint32_t device_assign_max_centroids();
+// Largest number of centroids a list may have to be clustered on `device` (others stay on the host): bounded by the
+// LDS a workgroup may have there. 0 = the device cannot be queried.
+uint32_t device_assign_max_centroids(int device);
 // cid_out[lp_off[c] + t] = index (within list c's centroids) of the centroid posting t of list c belongs
 // to, for every list with eligible[c] != 0. `top` holds doc_cut {component | ~0, f32 bits} pairs per document.
 sgpu_status device_assign_clusters(int device, uint32_t comp_width, uint64_t n_docs, uint64_t dim, uint64_t nnz,

@@ -537,6 +537,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
     std::vector<uint32_t> post_flat(lp_off[dim]), cent_flat(lc_off[dim]);
     const bool on_device = cfg.use_device != 0;
     std::vector<uint8_t> eligible(dim, 0);
+    const uint32_t dev_max_centroids = on_device ? device_assign_max_centroids((int)cfg.use_device - 1) : 0u;   // (by the device's LDS)
     uint64_t inv_cap = 0;
 #pragma omp parallel num_threads(nt)
     {
@@ -553,7 +554,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
         std::copy(pl.begin(), pl.end(), post_flat.begin() + (long)lp_off[(size_t)c]);
         sample_centroids(pl, cfg, cd);
         std::copy(cd.begin(), cd.end(), cent_flat.begin() + (long)lc_off[(size_t)c]);
-        if (on_device && cd.size() <= device_assign_max_centroids()) {
+        if (on_device && cd.size() <= dev_max_centroids) {
           eligible[(size_t)c] = 1;
           uint64_t entries = 0;
           for (uint32_t x : cd) entries += d.off[x + 1] - d.off[x];

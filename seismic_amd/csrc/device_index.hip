@@ -25,20 +25,23 @@ hipError_t run_u32_hash(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_dense_u8(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_packed_u8(const LaunchArgs& a, int* occupancy);
 hipError_t run_u32_packed_u8(const LaunchArgs& a, int* occupancy);
-hipError_t run_u16_hash(const LaunchArgs& a, int* occupancy);
-hipError_t run_u16_hash_u8(const LaunchArgs& a, int* occupancy);
 hipError_t run_u32_split_u8(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_dense_dvb(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_packed_dvb(const LaunchArgs& a, int* occupancy);
-hipError_t run_u16_hash_dvb(const LaunchArgs& a, int* occupancy);
+hipError_t run_u16_dense_f16s(const LaunchArgs& a, int* occupancy);
+hipError_t run_u16_packed_f16s(const LaunchArgs& a, int* occupancy);
 
 static hipError_t run_any(const LaunchArgs& a, int* occ) {
+  // (u16 components: dense byte table or packed {bits, rank} words. The hashed lookup is the u32 layout: for u16 it
+  // measured slower than both - 6.46 against 5.81 ms per 10 000-query launch, profiles/r03_lds_sensitivity.md - and its
+  // three families were dropped in r05)
+  if (a.comp_width == 2 && a.lookup != LK_DENSE && a.lookup != LK_PACKED) return hipErrorInvalidConfiguration;
+  if (a.value_type == kDevValF16Sliced) return a.lookup == LK_DENSE ? run_u16_dense_f16s(a, occ) : run_u16_packed_f16s(a, occ);
   if (a.value_type == SGPU_VAL_DOTVBYTE)   // (u16 components only)
-    return a.lookup == LK_HASH ? run_u16_hash_dvb(a, occ) : (a.lookup == LK_DENSE ? run_u16_dense_dvb(a, occ) : run_u16_packed_dvb(a, occ));
+    return a.lookup == LK_DENSE ? run_u16_dense_dvb(a, occ) : run_u16_packed_dvb(a, occ);
   if (a.value_type == SGPU_VAL_FIXEDU8 && a.comp_width == 4) return a.lookup == LK_SPLIT ? run_u32_split_u8(a, occ) : run_u32_packed_u8(a, occ);
-  if (a.value_type == SGPU_VAL_FIXEDU8)
-    return a.lookup == LK_HASH ? run_u16_hash_u8(a, occ) : (a.lookup == LK_DENSE ? run_u16_dense_u8(a, occ) : run_u16_packed_u8(a, occ));
-  if (a.comp_width == 2) return a.lookup == LK_HASH ? run_u16_hash(a, occ) : (a.lookup == LK_DENSE ? run_u16_dense(a, occ) : run_u16_packed(a, occ));
+  if (a.value_type == SGPU_VAL_FIXEDU8) return a.lookup == LK_DENSE ? run_u16_dense_u8(a, occ) : run_u16_packed_u8(a, occ);
+  if (a.comp_width == 2) return a.lookup == LK_DENSE ? run_u16_dense(a, occ) : run_u16_packed(a, occ);
   if (a.lookup == LK_HASH) return run_u32_hash(a, occ);
   return a.lookup == LK_SPLIT ? run_u32_split(a, occ) : run_u32_packed(a, occ);
 }
@@ -51,6 +54,12 @@ hipError_t launch_search(const LaunchArgs& a) { return run_any(a, nullptr); }
     if (e_ != hipSuccess)                                                                      \
       return fail(SGPU_EDEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+
+// (a test hook read outside the per-call knob cache: only while SGPU_TEST_HOOKS=1 is set; see hooks_on below)
+static const char* hook_raw(const char* name) {
+  const char* t = std::getenv("SGPU_TEST_HOOKS");
+  return (t && *t && *t != '0') ? std::getenv(name) : nullptr;
+}
 
 }  // namespace sgpu
 struct sgpu_batch;
@@ -101,6 +110,7 @@ struct DeviceIndex {
   std::vector<uint32_t> list_nb, list_np;   // blocks / postings per posting list (host copy)
   uint32_t max_nb = 0;
   uint32_t value_type = SGPU_VAL_F16;   // how the records store document values
+  bool fwd_sliced = false;        // an f16 index in the sliced layout (compressed component stream: kernel VT_F16S)
   float val_scale = 0.0f;
   bool fwd_block_major = false;   // forward store holds a copy of every posting's record, block by block
   bool coop_broken = false;       // a cooperative launch reported a protocol error: the variant stays off for this replica
@@ -192,7 +202,7 @@ static sgpu_status dev_copy(DeviceIndex* d, const T* src, size_t n, const T** ou
   if (hipMalloc(&p, bytes) != hipSuccess) return fail(SGPU_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
   d->allocs.push_back(Alloc{p, bytes, (size_t)((const char*)out - (const char*)d)});
   d->bytes += bytes;
-  if (std::getenv("SGPU_DEBUG_ALLOC")) std::fprintf(stderr, "sgpu alloc: field@%zu %p..%p\n", (size_t)((const char*)out - (const char*)d), p, (void*)((char*)p + bytes));
+  if (hook_raw("SGPU_DEBUG_ALLOC")) std::fprintf(stderr, "sgpu alloc: field@%zu %p..%p\n", (size_t)((const char*)out - (const char*)d), p, (void*)((char*)p + bytes));
   if (n) HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
   *out = (const T*)p;
   return SGPU_OK;
@@ -221,16 +231,16 @@ int device_count() {
 __global__ __launch_bounds__(256) void replicate_records_kernel(uint8_t* fwd, const uint64_t* __restrict__ doc_ref,
                                                                 const uint32_t* __restrict__ post_doc,
                                                                 const uint64_t* __restrict__ post_ref, uint64_t n_postings,
-                                                                uint32_t bytes_per_elem, uint32_t dvb) {
+                                                                uint32_t bytes_per_elem, uint32_t dvb, uint32_t val_bytes) {
   const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const uint32_t sub = threadIdx.x & 15;
   const uint64_t n_groups = ((uint64_t)gridDim.x * blockDim.x) >> 4;
   for (uint64_t p = g; p < n_postings; p += n_groups) {
     const uint64_t dst = post_ref[p], src = doc_ref[post_doc[p]];
     uint32_t n16;   // 16-byte units of the record
-    if (dvb && !(dst & 0x8000u)) {   // DotVByte: [ns x 12 B gaps][pad to 8][ns x 8 B codes]
-      const uint32_t ns = (((uint32_t)dst & 0x7fffu) + 7u) >> 3;
-      n16 = ((((ns * 12u + 7u) & ~7u) + ns * 8u) + 15u) >> 4;
+    if (dvb && !(dst & 0x8000u)) {   // sliced: [ns x 12 B gaps][pad to 8 / 16][ns x 8 values of 1 / 2 bytes]
+      const uint32_t ns = (((uint32_t)dst & 0x7fffu) + 7u) >> 3, vb8 = 8u * val_bytes;
+      n16 = ((((ns * 12u + vb8 - 1u) & ~(vb8 - 1u)) + ns * vb8) + 15u) >> 4;
     } else {
       const uint32_t len = (uint32_t)dst & (dvb ? 0x7fffu : 0xffffu);
       n16 = (((len + 7u) & ~7u) * bytes_per_elem + 15u) >> 4;
@@ -275,10 +285,18 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     // otherwise touch more lines than its size needs: at 16-byte alignment a 480-byte record straddles
     // ~4.75 lines, line-fitted 4.
     std::vector<uint64_t> rec_off16;
-    std::vector<uint8_t> dvb_raw;   // DotVByte: the documents that keep the raw record form (a gap too wide for its field)
-    pack_dvb_raw_flags(h, &dvb_raw);
+    std::vector<uint8_t> dvb_raw;   // sliced layouts: the documents that keep the raw record form (a gap too wide for its field)
+    // An f16 index over u16 components takes the SLICED layout (r05: the DotVByte index's compressed component stream in
+    // front of the binary16 values, 28 bytes per 8-element slice instead of 32; lossless, rows bit-identical; kernel
+    // VT_F16S) unless SGPU_FWD_STREAM=plain asks for the [components | values] records of r01 - r04.
     {
-      const char* env_line = std::getenv("SGPU_REC_LINE");
+      const char* fs = std::getenv("SGPU_FWD_STREAM");
+      const bool want = !(fs && std::strcmp(fs, "plain") == 0);
+      pack_dvb_raw_flags(h, want, &dvb_raw);
+      d->fwd_sliced = h.value_type == SGPU_VAL_F16 && !dvb_raw.empty();
+    }
+    {
+      const char* env_line = hook_raw("SGPU_REC_LINE");
       pack_record_offsets(h, dvb_raw, std::max<uint64_t>(16, env_line ? std::strtoul(env_line, nullptr, 10) : 128) / 16, &rec_off16);
     }
     if (rec_off16[h.n_docs] >= (1ull << 48)) return bail(fail(SGPU_ELIMIT, "forward index exceeds 48-bit record offsets"));
@@ -328,7 +346,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       d->allocs.push_back(Alloc{fp, fbytes, (size_t)((const char*)&d->view.fwd - (const char*)d)});
       d->bytes += fbytes;
       d->view.fwd = (const uint8_t*)fp;
-      if (std::getenv("SGPU_DEBUG_ALLOC")) std::fprintf(stderr, "sgpu alloc: fwd %p..%p\n", fp, (void*)((char*)fp + fbytes));
+      if (hook_raw("SGPU_DEBUG_ALLOC")) std::fprintf(stderr, "sgpu alloc: fwd %p..%p\n", fp, (void*)((char*)fp + fbytes));
       HIP_TRY(hipMemcpy(fp, fwd.data(), fwd.size(), hipMemcpyHostToDevice));
     }
     fwd.clear();
@@ -345,7 +363,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     if (d->fwd_block_major && h.n_postings()) {
       hipLaunchKernelGGL(replicate_records_kernel, dim3(d->n_cu * 8), dim3(256), 0, d->main.stream,
                          (uint8_t*)d->view.fwd, d->view.doc_ref, d->view.post_doc, d->view.post_ref,
-                         (uint64_t)h.n_postings(), (uint32_t)(cw + vb), (uint32_t)(h.value_type == SGPU_VAL_DOTVBYTE));
+                         (uint64_t)h.n_postings(), (uint32_t)(cw + vb), (uint32_t)(!dvb_raw.empty()), (uint32_t)vb);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(d->main.stream));
     }
@@ -437,6 +455,7 @@ sgpu_status device_index_clone(const DeviceIndex* src, int device, DeviceIndex**
   d->max_nb = src->max_nb;
   d->fwd_block_major = src->fwd_block_major;
   d->value_type = src->value_type;
+  d->fwd_sliced = src->fwd_sliced;
   d->val_scale = src->val_scale;
   auto bail = [&](sgpu_status s) {
     device_index_free(d);
@@ -561,6 +580,16 @@ static uint32_t env_u32(const char* name, uint32_t dflt) {
   if (!v || !*v) return dflt;
   return (uint32_t)std::strtoul(v, nullptr, 10);
 }
+// The runtime knobs of the library are the ones INTEGRATION.md section 5 lists (read with env_get / env_u32). Every other
+// SGPU_* name is a TEST HOOK - it forces a code path the launch configuration would not choose by itself (small item
+// tables, a lookup layout, cooperative chunk sizes ...) - and is honoured only while SGPU_TEST_HOOKS=1 is set, which
+// tests/conftest.py and the tools under tools/ do: a deployment's behaviour does not depend on them.
+static bool hooks_on() {
+  const char* v = env_get("SGPU_TEST_HOOKS");
+  return v && *v && *v != '0';
+}
+static uint32_t hook_u32(const char* name, uint32_t dflt) { return hooks_on() ? env_u32(name, dflt) : dflt; }
+static const char* hook_get(const char* name) { return hooks_on() ? env_get(name) : nullptr; }
 
 // ---- host-side breakdown of a staged call (tools/latency_probe.py, sgpu_search_sequential) ----
 // A thread that sets call_timing() gets the wall time of every phase of its staged calls added up:
@@ -593,11 +622,10 @@ struct PhaseClock {
 // (done / done_seq: the launch stores done_seq into *done - pinned host memory - once every result row is there: the
 // wait ends then, whether or not the launch itself has ended)
 static hipError_t wait_lane(hipStream_t s, uint32_t nq, const volatile uint32_t* done = nullptr, uint32_t done_seq = 0) {
-  static const int mode = [] {
-    const char* v = std::getenv("SGPU_WAIT");
-    return (v && !std::strcmp(v, "block")) ? 0 : ((v && !std::strcmp(v, "spin")) ? 2 : 1);
-  }();
-  static const double spin_us = (double)env_u32("SGPU_SPIN_US", 2000);
+  // (both knobs are read through the per-call cache, like every other one: a test that flips them is not silently ignored)
+  const char* wv = env_get("SGPU_WAIT");
+  const int mode = (wv && !std::strcmp(wv, "block")) ? 0 : ((wv && !std::strcmp(wv, "spin")) ? 2 : 1);
+  const double spin_us = (double)env_u32("SGPU_SPIN_US", 2000);
   if (mode == 2 || (mode == 1 && nq <= 256)) {
     const double t0 = now_us();
     for (;;) {
@@ -790,15 +818,9 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
     for (uint32_t i = 0; i < nq; ++i) pl.order[i] = cost[i].second;
     // LK_HASH seeds: the first multiplier of the family that sends the query's components to distinct slots
     // (component ids below 2^24; a query may fill at most a quarter of the table)
-    pl.hash_ok = d->view.dim < (1u << 24) && !env_u32("SGPU_NO_HASH", 0);
-    if (pl.hash_ok && d->comp_width == 2 && d->view.dim <= 40000 && !env_u32("SGPU_FORCE_HASH", 0) && !env_u32("SGPU_NO_DENSE", 0)) {
-      // u16 components, a vocabulary whose dense byte table fits next to a second workgroup per CU: that table
-      // serves the batch (configure prefers it) unless a query has more than 255 components - the seeds (a
-      // millisecond of host time per 10 000 queries) are then not needed
-      bool dense_serves = true;
-      for (uint32_t q = 0; q < nq && dense_serves; ++q) dense_serves = h_off[q + 1] - h_off[q] <= 255;
-      if (dense_serves) pl.hash_ok = false;
-    }
+    // (only u32 components with f16 values have hashed kernels: configure; the seeds cost a millisecond of host time per
+    // 10 000 queries and are not computed for the others)
+    pl.hash_ok = d->view.dim < (1u << 24) && d->comp_width == 4 && d->value_type == SGPU_VAL_F16 && !hook_u32("SGPU_NO_HASH", 0);
     if (pl.hash_ok) {
       std::vector<uint32_t> stamp(kHashSlots, 0xffffffffu);
       uint32_t epoch = 0;
@@ -878,8 +900,11 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   if (std::isnan(sp.heap_factor)) return fail(SGPU_EINVAL, "heap_factor is NaN");
   // 512 threads x 2 workgroups per CU for throughput; when the batch has no more queries than
   // CUs, one 1024-thread workgroup per query (twice the scoring lanes) is ~20% faster
-  const uint32_t NT = env_u32("SGPU_BLOCK", (mode != MODE_DOTS && b->nq <= d->n_cu) ? 1024 : 512);
+  uint32_t NT = hook_u32("SGPU_BLOCK", (mode != MODE_DOTS && b->nq <= d->n_cu) ? 1024 : 512);
   if (NT != 512 && NT != 1024) return fail(SGPU_EINVAL, "SGPU_BLOCK must be 512 or 1024");
+  // (1024-thread variants exist for k <= 128 and never for the counted pass: device_types.hpp, variant_built)
+  const bool want_counted = mode == MODE_COUNTED || hook_u32("SGPU_VISITED_BITMAP", 0);
+  if (NT == 1024 && (want_counted || heap_variant(sp.k) > 2)) NT = 512;
   const uint32_t qn = std::max<uint32_t>(4, (b->max_nnz + 3u) & ~3u);
   const bool searching = mode != MODE_DOTS;
   // lists walked per query. query_cut == 0 walks none: the reference's k_largest_by(0) selects no
@@ -887,7 +912,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   const uint32_t cut = mode == MODE_DOTS ? 1u : std::min<uint32_t>(sp.query_cut, qn);
   const uint32_t qc = std::max<uint32_t>(1, cut);
   const uint32_t words = d->view.dim / 32 + 1;   // + the word of the padding sentinel `dim`
-  uint32_t items_max = env_u32("SGPU_ITEMS_MAX", 1024);
+  uint32_t items_max = hook_u32("SGPU_ITEMS_MAX", 1024);
   uint32_t dots_cap = 1, sort_nb = 0;
   const sgpu_batch_plan* pl = nullptr;
   if (mode == MODE_DOTS) {
@@ -914,7 +939,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   }
   L.q_comp = (uint32_t)o; o += up((uint64_t)qn * 4);
   L.sel = (uint32_t)o; o += up((6ull * qc + 1) * 4);
-  const uint64_t target = env_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
+  const uint64_t target = hook_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
   // what the layout needs besides the row tables and the block dots (the dense lookup table where it may be used)
   const uint64_t rest = up((sp.first_sorted && searching) ? (uint64_t)sort_nb * 2 : 0) + up(2 * (NT / 64 + 1) * 4) +
                         up((uint64_t)heap_variant(sp.k) * 64 * 8) +
@@ -931,7 +956,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   auto rt_bytes = [&](uint64_t g) { return up(g * qn * 8) + up(g * qn * 2) + up(2ull * g * (qn + 1) * 4); };
   uint32_t qg = qc;
   if (pl && qc > 4 && o + rt_bytes(qc) + rest + (uint64_t)dots_cap * 4 > target) qg = 4;
-  qg = std::max<uint32_t>(1, std::min<uint32_t>(qg, env_u32("SGPU_LIST_GROUP", qc)));
+  qg = std::max<uint32_t>(1, std::min<uint32_t>(qg, hook_u32("SGPU_LIST_GROUP", qc)));
   if (o + rt_bytes(qg) > lds_limit)
     return fail(SGPU_ELIMIT, "query_cut %u x %u query components do not fit the row tables in LDS", qc, qn);
   L.rt_start = (uint32_t)o; o += up((uint64_t)qg * qn * 8);
@@ -944,7 +969,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     const uint64_t fit = target > o + rest ? (target - o - rest) / 4 : 0;
     dots_cap = (uint32_t)std::max<uint64_t>(pl->max_list_nb, std::min<uint64_t>(dots_cap, std::max<uint64_t>(fit, 6144)));
   }
-  dots_cap = std::min<uint32_t>(dots_cap, env_u32("SGPU_DOTS_CAP", 0xffffffffu));
+  dots_cap = std::min<uint32_t>(dots_cap, hook_u32("SGPU_DOTS_CAP", 0xffffffffu));
   if (pl) dots_cap = std::max(dots_cap, pl->max_list_nb);
   L.dots_cap = dots_cap;
   L.dots = (uint32_t)o; o += up((uint64_t)dots_cap * 4);
@@ -962,18 +987,18 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   if (o > lds_limit)
     return fail(SGPU_ELIMIT, "query needs %llu bytes of LDS before its lookup table (dots %u blocks) > %llu available",
                 (unsigned long long)o, dots_cap, (unsigned long long)lds_limit);
-  const uint64_t budget = env_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
+  const uint64_t budget = hook_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
   // query lookup table: dense u8 index (1 B per vocabulary id + the padding sentinel) when it is
   // allowed and fits at 2 workgroups per CU, else {bits, rank} per 32 vocabulary ids
   const uint64_t dense_bytes = up((uint64_t)d->view.dim + 1), bitmap_bytes = up((uint64_t)words * 8);
   const bool dense_ok = d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255 &&
-                        !env_u32("SGPU_NO_DENSE", 0) && searching;
+                        !hook_u32("SGPU_NO_DENSE", 0) && searching;
   const uint64_t split_bits = up((uint64_t)words * 4), split_bytes = split_bits + up((uint64_t)words * 2);
   // the round's item tables shrink (down to 256 items) if that is what keeps 2 workgroups per CU
   auto uni_for = [&](uint32_t items) { return up(std::max<uint64_t>((uint64_t)items * 16 + NT * 12, sort_bytes)); };
   const uint64_t smallest_lookup = (d->comp_width == 4) ? split_bytes : bitmap_bytes;
   const uint32_t want_items = items_max;
-  if (!env_get("SGPU_ITEMS_MAX")) {
+  if (!hook_get("SGPU_ITEMS_MAX")) {
     const uint32_t want = items_max;
     if (dense_ok)   // the dense table is worth smaller rounds (down to 512 items)
       while (items_max > 512 && o + dense_bytes + uni_for(items_max) > budget) items_max -= 128;
@@ -983,32 +1008,32 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     }
   }
   const uint64_t min_uni = uni_for(items_max);
-  const bool dense = dense_ok && (o + dense_bytes + min_uni <= budget || env_u32("SGPU_FORCE_DENSE", 0));
+  const bool dense = dense_ok && (o + dense_bytes + min_uni <= budget || hook_u32("SGPU_FORCE_DENSE", 0));
   // large vocabularies: bits + 16-bit ranks (6 B per 32 ids) when the packed table (8 B) would
   // cost the second workgroup per CU
   const bool split = !dense && d->comp_width == 4 && b->max_nnz <= 65535 &&
-                     (o + bitmap_bytes + min_uni > budget || env_u32("SGPU_FORCE_SPLIT", 0)) &&
-                     !env_u32("SGPU_NO_SPLIT", 0);
+                     (o + bitmap_bytes + min_uni > budget || hook_u32("SGPU_FORCE_SPLIT", 0)) &&
+                     !hook_u32("SGPU_NO_SPLIT", 0);
   // hashed {component id, weight} entries (32 KB): ONE LDS read per document component where the dense byte
   // table needs two (profiles/r03_lds_sensitivity.md) - preferred whenever every query of the batch has a
   // collision-free seed, the launch order (which carries the seeds) is in use, and it fits at 2 workgroups
   // per CU (the round's item tables shrink for it as they do for the dense table)
   const uint64_t hash_bytes = (uint64_t)kHashSlots * 8;
-  const bool hash_family = !(d->comp_width == 4 && d->value_type == SGPU_VAL_FIXEDU8);   // (no u32 + fixed-u8 hashed kernels)
+  const bool hash_family = d->comp_width == 4 && d->value_type == SGPU_VAL_F16;   // (the hashed kernels: u32 components, f16 values)
   // (measured r03 on the 8.8M-document shape, u16 components: 6.46 ms per launch against the dense byte
   // table's 5.81 - a random 8-byte read costs two bank passes where the byte read costs one and the dense
   // layout's second read is mostly a broadcast of one address; fixed-u8 6.36 against 5.56. The hashed
   // entries therefore serve u32 components, where they replace a byte read PLUS an 8-byte read; for u16
   // they are used when the dense table is not available or on request, SGPU_FORCE_HASH=1.)
-  bool hashed = searching && hash_family && pl && pl->hash_ok && !env_u32("SGPU_NO_LPT", 0) && !env_u32("SGPU_NO_HASH", 0) &&
-                !env_u32("SGPU_FORCE_SPLIT", 0) && !env_u32("SGPU_FORCE_DENSE", 0) &&
-                (d->comp_width == 4 || !dense || env_u32("SGPU_FORCE_HASH", 0));
-  if (hashed && !env_get("SGPU_ITEMS_MAX") && !env_u32("SGPU_FORCE_HASH", 0)) {
+  bool hashed = searching && hash_family && pl && pl->hash_ok && !hook_u32("SGPU_NO_LPT", 0) && !hook_u32("SGPU_NO_HASH", 0) &&
+                !hook_u32("SGPU_FORCE_SPLIT", 0) && !hook_u32("SGPU_FORCE_DENSE", 0) &&
+                (d->comp_width == 4 || !dense || hook_u32("SGPU_FORCE_HASH", 0));
+  if (hashed && !hook_get("SGPU_ITEMS_MAX") && !hook_u32("SGPU_FORCE_HASH", 0)) {
     uint32_t im = want_items;
     while (im > 512 && o + hash_bytes + uni_for(im) > budget) im -= 128;
     if (o + hash_bytes + uni_for(im) <= budget) items_max = im;
     else hashed = false;
-  } else if (hashed && !env_u32("SGPU_FORCE_HASH", 0) && o + hash_bytes + uni_for(items_max) > budget) {
+  } else if (hashed && !hook_u32("SGPU_FORCE_HASH", 0) && o + hash_bytes + uni_for(items_max) > budget) {
     hashed = false;
   }
   const uint32_t lookup = hashed ? LK_HASH : (dense ? LK_DENSE : (split ? LK_SPLIT : LK_PACKED));
@@ -1037,15 +1062,15 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->p.first_sorted = sp.first_sorted != 0;
   a->p.mode = mode == MODE_COUNTED ? (uint32_t)MODE_SEARCH : mode;
   a->p.n_knn = mode == MODE_DOTS ? 0u : sp.n_knn;   // ignored when the index has no graph, as the reference does
-  a->counted = (mode == MODE_COUNTED || env_u32("SGPU_VISITED_BITMAP", 0)) ? 1u : 0u;
+  a->counted = want_counted ? 1u : 0u;
   a->p.items_max = items_max;
-  a->p.items_init = std::min<uint32_t>(items_max, env_u32("SGPU_ITEMS_INIT", 128));
-  a->p.items_min = std::min<uint32_t>(a->p.items_init, env_u32("SGPU_ITEMS_MIN", 64));
-  a->p.rblocks_max = std::min<uint32_t>(32, std::max<uint32_t>(1, env_u32("SGPU_RBLOCKS", 8)));   // one mask bit per block
+  a->p.items_init = std::min<uint32_t>(items_max, hook_u32("SGPU_ITEMS_INIT", 128));
+  a->p.items_min = std::min<uint32_t>(a->p.items_init, hook_u32("SGPU_ITEMS_MIN", 64));
+  a->p.rblocks_max = std::min<uint32_t>(32, std::max<uint32_t>(1, hook_u32("SGPU_RBLOCKS", 8)));   // one mask bit per block
   a->p.target_list = mode == MODE_DOTS ? sp.query_cut : 0;
   a->p.val_scale = d->val_scale;
   a->p.queue_base = b->staged ? b->queue_base : 0u;
-  a->value_type = d->value_type;
+  a->value_type = d->fwd_sliced ? (uint32_t)kDevValF16Sliced : d->value_type;
   a->ix = d->view;
   a->comp_width = d->comp_width;
   a->block = NT;
@@ -1064,7 +1089,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->qb.out_n = b->out_n;
   a->qb.q_order = nullptr;
   a->qb.q_seed = nullptr;
-  if (pl && !env_u32("SGPU_NO_LPT", 0) && b->nq) {
+  if (pl && !hook_u32("SGPU_NO_LPT", 0) && b->nq) {
     // the processing order lives in the batch's own device buffer (no allocation on the path)
     if (b->order_cut != cut) {
       if (b->order_cut != 0xffffffffu) HIP_TRY(hipStreamSynchronize(lane->stream));   // the staging copy may be in flight
@@ -1089,13 +1114,14 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     // from ~1000 queries per launch on the variant's own cost - 6 % slower rounds, idle workgroups kept
     // resident - outweighs what its tail help returns: 780 vs 742 us)
     const uint32_t max_nq = env_u32("SGPU_COOP_MAX_NQ", d->n_cu);
-    if (!off && !a->counted && mode == MODE_SEARCH && a->lds_bytes - a->L.uni >= 4096 && (force || b->nq <= max_nq))
+    if (!off && !a->counted && mode == MODE_SEARCH && a->lds_bytes - a->L.uni >= 4096 && (force || b->nq <= max_nq) &&
+        variant_built(NT, heap_variant(sp.k), false, true))   // (k > 256: the plain variant)
       a->coop.enabled = force ? 2u : 1u;
   }
   // occupancy of this kernel variant at this LDS size: queried once, then remembered
   int per_cu = 0;
   {
-    const uint64_t key = ((uint64_t)(a->coop.enabled != 0) << 58) | ((uint64_t)a->comp_width << 56) | ((uint64_t)a->counted << 55) | ((uint64_t)a->value_type << 54) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
+    const uint64_t key = ((uint64_t)(a->coop.enabled != 0) << 58) | ((uint64_t)a->comp_width << 56) | ((uint64_t)a->counted << 55) | ((uint64_t)a->value_type << 52) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
                          ((uint64_t)heap_variant(a->p.k) << 28) | (uint64_t)(a->lds_bytes >> 4);
     auto it = d->occupancy.find(key);
     if (it == d->occupancy.end()) {
@@ -1106,7 +1132,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     }
   }
   if (per_cu < 1) return fail(SGPU_ELIMIT, "the search kernel does not fit on a CU with %llu bytes of LDS", (unsigned long long)o);
-  const uint32_t cap = env_u32("SGPU_WG_PER_CU", 0);
+  const uint32_t cap = hook_u32("SGPU_WG_PER_CU", 0);
   if (cap && (uint32_t)per_cu > cap) per_cu = (int)cap;
   uint32_t grid = d->n_cu * (uint32_t)per_cu;
   // Cooperative variant (small launches and their tails; DESIGN.md "Cooperative mode"): every slot of the
@@ -1124,7 +1150,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
       // 256 -> 228, 361 -> 326 us); two queries are best served by 96 - 128 (157 -> 146 us), eight by 128 - 256 (+-1 %),
       // 32 and more by all of them. Rule: 48 + 32 per query, scaled to the chip's CU count. SGPU_COOP_GRID overrides.
       const uint32_t rule = (uint32_t)(((uint64_t)48 + 32ull * b->nq) * d->n_cu / 256);
-      uint32_t cg = env_u32("SGPU_COOP_GRID", 0xffffffffu);   // unset: the rule; 0: every slot; n: at most n workgroups
+      uint32_t cg = hook_u32("SGPU_COOP_GRID", 0xffffffffu);   // unset: the rule; 0: every slot; n: at most n workgroups
       if (cg == 0xffffffffu) cg = std::max<uint32_t>(rule, 8);
       if (cg) grid = std::max<uint32_t>(std::min<uint32_t>(grid, cg), std::min<uint32_t>(b->nq, grid));
     }
@@ -1135,15 +1161,18 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     if (a->coop.enabled) {
       CoopView& c = a->coop;
       c.max_pos = std::min<uint32_t>(65535u, std::max<uint32_t>(a->L.dots_cap, 1u));
-      c.max_cand = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(env_u32("SGPU_COOP_MAX_CAND", 1024), NT), uni_bytes / 20);
-      c.chunk = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(std::max<uint32_t>(env_u32("SGPU_COOP_CHUNK", 128), 1u), std::min<uint32_t>(NT, 1023u)),
+      c.max_cand = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(hook_u32("SGPU_COOP_MAX_CAND", 1024), NT), uni_bytes / 20);
+      c.chunk = (uint32_t)std::min<uint64_t>(std::min<uint32_t>(std::max<uint32_t>(hook_u32("SGPU_COOP_CHUNK", 128), 1u), std::min<uint32_t>(NT, 1023u)),
                                              uni_bytes / 16);
-      c.chunk_min = std::min<uint32_t>(c.chunk, std::max<uint32_t>(env_u32("SGPU_COOP_CHUNK_MIN", 4), 1u));
-      c.min_items = env_u32("SGPU_COOP_MIN_ITEMS", 64);
-      c.first_reach = std::max<uint32_t>(1, env_u32("SGPU_COOP_FIRST_REACH", 256));
-      c.idle_min = env_u32("SGPU_COOP_IDLE_MIN", force ? 0 : 8);
-      c.idle_ratio = env_u32("SGPU_COOP_IDLE_RATIO", force ? 0 : 8);
-      c.poll_sleep = std::max<uint32_t>(1, env_u32("SGPU_COOP_POLL", 2));
+      c.chunk_min = std::min<uint32_t>(c.chunk, std::max<uint32_t>(hook_u32("SGPU_COOP_CHUNK_MIN", 4), 1u));
+      c.min_items = hook_u32("SGPU_COOP_MIN_ITEMS", 64);
+      c.first_reach = std::max<uint32_t>(1, hook_u32("SGPU_COOP_FIRST_REACH", 256));
+      c.idle_min = hook_u32("SGPU_COOP_IDLE_MIN", force ? 0 : 8);
+      // (r05: an owner goes wide once there is ONE idle workgroup per workgroup still owning a query - until r04 eight, which
+      // kept the 64 owners of a 64-query launch on their own although 192 helpers were resident: 324 -> 221 us per launch,
+      // 256 queries 442 -> 380 us; gpurun_out r05c, profiles/r05_coop_policy.txt)
+      c.idle_ratio = hook_u32("SGPU_COOP_IDLE_RATIO", force ? 0 : 1);
+      c.poll_sleep = std::max<uint32_t>(1, hook_u32("SGPU_COOP_POLL", 2));
       c.enabled = 1u;
       const size_t o_slots = 128, o_pos = o_slots + (size_t)grid * kCoopSlotWords * 8,
                    o_cand = o_pos + (size_t)grid * c.max_pos * 8, o_trace = o_cand + (size_t)grid * c.max_cand * 16,
@@ -1159,7 +1188,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
           return fail(SGPU_ENOMEM, "hipMalloc of the %zu-byte cooperative board failed", total);
         lane->coop_bytes = total;
         HIP_TRY(hipMemsetAsync(lane->coop, 0, total, lane->stream));
-      } else if (lane->coop_bytes && env_u32("SGPU_COOP_RESET", 0)) {   // (debugging aid: do not trust the kernel's own clean-up)
+      } else if (lane->coop_bytes && hook_u32("SGPU_COOP_RESET", 0)) {   // (debugging aid: do not trust the kernel's own clean-up)
         HIP_TRY(hipMemsetAsync(lane->coop, 0, o_pos, lane->stream));
       }
       if (env_u32("SGPU_DEBUG", 0))
@@ -1172,7 +1201,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
       c.pos_pub = (uint64_t*)(lane->coop + o_pos);
       c.cands = (uint64_t*)(lane->coop + o_cand);
       c.trace = nullptr;
-      if (env_u32("SGPU_COOP_TRACE", 0)) {   // (trace builds) the timeline of this launch: zeroed here, dumped by coop_trace_dump
+      if (hook_u32("SGPU_COOP_TRACE", 0)) {   // (trace builds) the timeline of this launch: zeroed here, dumped by coop_trace_dump
         c.trace = (uint64_t*)(lane->coop + o_trace);
         HIP_TRY(hipMemsetAsync(lane->coop + o_trace, 0, (size_t)grid * 16 * 8, lane->stream));
         lane->coop_trace_off = o_trace;
@@ -1181,8 +1210,8 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     }
   }
   // latency-bound launches bootstrap the threshold with ONE local round before they go wide
-  if (a->coop.enabled && b->nq <= d->n_cu && !env_get("SGPU_ITEMS_INIT"))
-    a->p.items_init = std::min<uint32_t>(a->p.items_max, std::max<uint32_t>(1, env_u32("SGPU_COOP_ITEMS_INIT", 128)));
+  if (a->coop.enabled && b->nq <= d->n_cu && !hook_get("SGPU_ITEMS_INIT"))
+    a->p.items_init = std::min<uint32_t>(a->p.items_max, std::max<uint32_t>(1, hook_u32("SGPU_COOP_ITEMS_INIT", 128)));
   if (!a->coop.enabled) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
   a->grid = grid;
   // A cooperative launch that writes its rows straight into the pinned host arena also tells the host when the LAST
@@ -1383,9 +1412,12 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   HIP_TRY(hipSetDevice(d->device));
   const uint64_t nnz = q_off[nq];
   const uint32_t k = sp.k;
-  // arena: [work counter 16 B | q_off | q_comp | q_val | order | status 16 B]  ->  [status | out_n | out_scores | out_ids]
-  // (the status word goes down zeroed with the input and comes back with the rows)
-  const size_t o_off = 16, o_comp = o_off + al16((size_t)(nq + 1) * 4), o_val = o_comp + al16(nnz * 4),
+  // arena: [work counter 16 B | fixed status 16 B | q_off | q_comp | q_val | order | status 16 B]  ->  [status | out_n | out_scores | out_ids]
+  // (the trailing status word goes down zeroed with the input and comes back with the rows in one D2H copy; a launch that
+  // writes its rows straight into the pinned host arena uses the FIXED status / done words instead: their address does not
+  // move with nq and nnz, so a launch that is still winding down when the lane's next call stages its input - early done -
+  // can only ever touch those two words, never the next call's queries)
+  const size_t o_fix = 16, o_off = 32, o_comp = o_off + al16((size_t)(nq + 1) * 4), o_val = o_comp + al16(nnz * 4),
                o_order = o_val + al16(nnz * 4), o_status = o_order + al16((size_t)nq * 8),   // [order | hash seeds]
                in_bytes = o_status + 16;
   const size_t r_n = in_bytes, r_sc = r_n + al16((size_t)nq * 4), r_id = r_sc + al16((size_t)nq * k * 4),
@@ -1405,13 +1437,13 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     b->owner = d;
     b->arena_cap = std::max<size_t>(total + total / 4, 1 << 16);   // some room: a stream of similar calls settles
     if (hipMalloc((void**)&b->arena_dev, b->arena_cap) != hipSuccess ||
-        hipHostMalloc((void**)&b->arena_host, b->arena_cap, hipHostMallocMapped) != hipSuccess) {
+        hipHostMalloc((void**)&b->arena_host, b->arena_cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {   // (fine-grained by request, not by the runtime's default: the kernel's rows and done word must be visible as they land)
       batch_free(b);
       return fail(SGPU_ENOMEM, "allocation of a %zu-byte staging arena failed", b->arena_cap);
     }
     if (hipHostGetDevicePointer((void**)&b->arena_host_dev, b->arena_host, 0) != hipSuccess) b->arena_host_dev = nullptr;
     *slot = b;
-    if (std::getenv("SGPU_DEBUG_ALLOC")) std::fprintf(stderr, "sgpu alloc: arena %p..%p\n", (void*)b->arena_dev, (void*)(b->arena_dev + b->arena_cap));
+    if (hook_raw("SGPU_DEBUG_ALLOC")) std::fprintf(stderr, "sgpu alloc: arena %p..%p\n", (void*)b->arena_dev, (void*)(b->arena_dev + b->arena_cap));
   }
   b->nq = nq;
   b->k_max = k;
@@ -1419,8 +1451,10 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   b->in_bytes = in_bytes;
   b->out_off = r_n;
   b->out_bytes = total - r_n;
-  b->status_off = o_status;
-  if (nq == 0) return SGPU_OK;
+  if (nq == 0) {
+    b->status_off = o_status;
+    return SGPU_OK;
+  }
   const uint32_t qn = std::max<uint32_t>(4, (max_nnz + 3u) & ~3u);
   const uint32_t cut = std::min<uint32_t>(sp.query_cut, qn);
   try {
@@ -1442,14 +1476,15 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   }
   std::memcpy(hs + o_order, b->plans.back().order.data(), (size_t)nq * 8);
   std::memset(hs + o_status, 0, 16);
+  std::memset(hs + o_fix, 0, 16);
   // A latency-bound call (a handful of queries) has the kernel write its few result rows straight into the pinned
   // host arena (mapped, fine-grained: posted writes over PCIe, visible once the stream is done): no D2H copy to
   // enqueue, none to wait for. Larger calls keep the device-side slab and one D2H. Since r04 such a call also lets the
   // kernel READ its queries (a few hundred bytes) from that arena: no H2D copy to enqueue (5 us of host time and a
   // copy command ahead of the kernel) - which leaves the work counter: it is not zeroed per launch but runs on
   // (KParams::queue_base; Lane::queue_pos mirrors it on the host).
-  static const uint32_t direct_max = env_u32("SGPU_DIRECT_OUT_MAX", 16);
-  static const uint32_t direct_in_on = env_u32("SGPU_DIRECT_IN", 1);
+  const uint32_t direct_max = hook_u32("SGPU_DIRECT_OUT_MAX", 16);   // (read per call: the knob cache is refreshed per call)
+  const uint32_t direct_in_on = env_u32("SGPU_DIRECT_IN", 1);
   b->direct_out = b->arena_host_dev != nullptr && nq <= direct_max;
   b->direct_in = b->direct_out && direct_in_on != 0;
   uint8_t* in_base = b->direct_in ? b->arena_host_dev : b->arena_dev;
@@ -1465,7 +1500,8 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   b->out_scores = (float*)(out_base + r_sc);
   b->out_ids = (uint64_t*)(out_base + r_id);
   b->out_stats = nullptr;
-  b->status = (uint32_t*)(out_base + o_status);
+  b->status_off = b->direct_out ? o_fix : o_status;
+  b->status = (uint32_t*)(out_base + b->status_off);
   pc.lap(1);
   if (b->direct_in) {
     if (lane->queue_dirty) {   // first use of the lane, or a launch on it failed: the counter's value is not known
@@ -1593,7 +1629,7 @@ sgpu_status build_knn_on_device(DeviceIndex* d, HostIndex& h, uint32_t nknn) {
   if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
   if (nknn == 0 || nknn + 1 > 1024) return fail(SGPU_EINVAL, "nknn must be in 1..1023");
   const uint32_t k = nknn + 1;
-  const uint64_t chunk = env_u32("SGPU_KNN_CHUNK", 32768);
+  const uint64_t chunk = hook_u32("SGPU_KNN_CHUNK", 32768);
   std::vector<uint32_t> out;
   out.reserve((size_t)h.n_docs * nknn);
   sgpu_search_params sp{};

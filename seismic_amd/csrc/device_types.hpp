@@ -52,6 +52,9 @@ struct BatchView {
                            //   left its writer - the host may hand the rows out while the launch winds down
 };
 
+// LaunchArgs::value_type is SGPU_VAL_* (seismic_hip.h: 0 f16, 1 fixed-u8, 2 DotVByte) or this internal layout of an f16
+// index: binary16 values behind the compressed component stream (search_kernel.inc VT_F16S; chosen at upload)
+enum { kDevValF16Sliced = 3 };
 enum { MODE_SEARCH = 0, MODE_DOTS = 1, MODE_COUNTED = 2 };   // COUNTED: search with the visited bitmap (exact counters)
 // query lookup table in LDS: {32 bits, rank} per 32 ids | one byte per id | bits + 16-bit ranks | hashed {id, weight} entries
 enum { LK_PACKED = 0, LK_DENSE = 1, LK_SPLIT = 2, LK_HASH = 3 };
@@ -164,5 +167,17 @@ hipError_t launch_search(const LaunchArgs& a);
 
 // Registers of wavefront 0 per heap entry array (RegHeap<KR>): the kernel variant that serves k.
 inline uint32_t heap_variant(uint32_t k) { return k <= 64 ? 1u : (k <= 128 ? 2u : (k <= 256 ? 4u : (k <= 512 ? 8u : 16u))); }
+// Which (workgroup size, heap registers, counted, cooperative) combinations the library instantiates per kernel family:
+//   plain        512 threads: every k (<= 1024);  1024 threads (launches of at most n_cu queries): k <= 128
+//   counted      512 threads only (the accounting pass is not a latency path)
+//   cooperative  512 threads: k <= 256;  1024 threads: k <= 128  (larger k: the plain variant)
+// 17 symbols per family (r04: 30, of which the k > 256 cooperative and 1024-thread ones spilled 190 - 230 VGPRs and
+// were never chosen by a benchmark configuration).
+inline bool variant_built(uint32_t block, uint32_t kr, bool counted, bool coop) {
+  if (block != 512 && block != 1024) return false;
+  if (counted) return block == 512;
+  if (block == 1024) return kr <= 2;
+  return coop ? kr <= 4 : true;
+}
 
 }  // namespace sgpu

@@ -35,20 +35,47 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
   const int nt = 1;
 #endif
   try {
-    // full inverted file (component -> (doc, value)), docs ascending within a list
+    // full inverted file (component -> (doc, value)), docs ascending within a list: a counting sort, the documents cut
+    // into one contiguous range per thread (a thread's entries of a component follow those of the threads before it)
     std::vector<uint64_t> ptr(ix.dim + 1, 0);
-    for (uint64_t i = 0; i < nnz; ++i) ptr[ix.comp(i) + 1]++;
-    for (uint64_t c = 0; c < ix.dim; ++c) ptr[c + 1] += ptr[c];
     std::vector<uint32_t> idoc(nnz);
     std::vector<float> ival(nnz);   // document values widened once (exact for f16 and fixed-u8)
     {
-      std::vector<uint64_t> cur(ptr.begin(), ptr.end() - 1);
-      for (uint64_t d = 0; d < ix.n_docs; ++d)
-        for (uint64_t i = ix.fwd_offsets[d]; i < ix.fwd_offsets[d + 1]; ++i) {
-          const uint64_t p = cur[ix.comp(i)]++;
-          idoc[p] = (uint32_t)d;
-          ival[p] = ix.val(i);
+      const int bt = nt < 1 ? 1 : nt;
+      std::vector<uint64_t> cur((size_t)bt * ix.dim, 0);   // [thread][component]: count, then first slot
+      auto range = [&](int t, uint64_t* d0, uint64_t* d1) {
+        *d0 = ix.n_docs * (uint64_t)t / (uint64_t)bt;
+        *d1 = ix.n_docs * (uint64_t)(t + 1) / (uint64_t)bt;
+      };
+#pragma omp parallel for num_threads(bt) schedule(static, 1)
+      for (int t = 0; t < bt; ++t) {
+        uint64_t d0, d1;
+        range(t, &d0, &d1);
+        uint64_t* c = cur.data() + (size_t)t * ix.dim;
+        for (uint64_t i = ix.fwd_offsets[d0]; i < ix.fwd_offsets[d1]; ++i) c[ix.comp(i)]++;
+      }
+      uint64_t run = 0;
+      for (uint64_t c = 0; c < ix.dim; ++c) {
+        ptr[c] = run;
+        for (int t = 0; t < bt; ++t) {
+          const uint64_t n = cur[(size_t)t * ix.dim + c];
+          cur[(size_t)t * ix.dim + c] = run;
+          run += n;
         }
+      }
+      ptr[ix.dim] = run;
+#pragma omp parallel for num_threads(bt) schedule(static, 1)
+      for (int t = 0; t < bt; ++t) {
+        uint64_t d0, d1;
+        range(t, &d0, &d1);
+        uint64_t* c = cur.data() + (size_t)t * ix.dim;
+        for (uint64_t d = d0; d < d1; ++d)
+          for (uint64_t i = ix.fwd_offsets[d]; i < ix.fwd_offsets[d + 1]; ++i) {
+            const uint64_t p = c[ix.comp(i)]++;
+            idoc[p] = (uint32_t)d;
+            ival[p] = ix.val(i);
+          }
+      }
     }
     // per-thread scratch is sized here, where an allocation failure reaches the enclosing try; inside
     // the parallel region a failure (growth of the small vectors) is caught per query and flagged

@@ -68,7 +68,9 @@ sgpu_status validate_queries(uint64_t dim, const uint64_t* q_off, const uint32_t
 sgpu_status validate_query_offsets(const uint64_t* q_off, uint32_t nq, uint32_t q_base, uint32_t* max_nnz);
 // pack_index.cpp: the host half of the upload (HBM layout of DESIGN.md section 2), on all host cores
 // (raw: per document, 1 = a DotVByte index keeps the document in the raw record form; empty for the other value types)
-void pack_dvb_raw_flags(const HostIndex& h, std::vector<uint8_t>* raw);
+// (f16_slices: also give an f16 index over u16 components the compressed component stream - search_kernel.inc VT_F16S)
+bool pack_f16_slices_possible(const HostIndex& h);
+void pack_dvb_raw_flags(const HostIndex& h, bool f16_slices, std::vector<uint8_t>* raw);
 void pack_record_offsets(const HostIndex& h, const std::vector<uint8_t>& raw, uint64_t line16, std::vector<uint64_t>* rec_off16);
 void pack_records(const HostIndex& h, const std::vector<uint8_t>& raw, const std::vector<uint64_t>& rec_off16, std::vector<uint8_t>* fwd);
 void pack_block_sizes(const HostIndex& h, const std::vector<uint8_t>& raw, std::vector<uint64_t>* bsize);

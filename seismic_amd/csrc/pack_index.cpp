@@ -9,37 +9,48 @@
 
 namespace sgpu {
 
-// ---- DotVByte forward index (SGPU_VAL_DOTVBYTE; search_kernel.inc: VT_DVB) ---------------------------------------
+// ---- compressed component stream (SGPU_VAL_DOTVBYTE: search_kernel.inc VT_DVB; and, since r05, the sliced layout of an
+// f16 index over u16 components: VT_F16S) ---------------------------------------------------------------------------
 // A document is stored as 12-byte slices of eight elements - the slice's first component in 16 bits, the gaps of
 // elements 1 .. 3 in 12 bits each, those of elements 4 .. 7 in 11 bits each - when every gap fits its field; otherwise
-// it keeps the raw (fixed-u8) record form and its refs carry kDvbRawBit in the length field.
+// it keeps the raw record form and its refs carry kDvbRawBit in the length field. `raw` is EMPTY for an index that is
+// not sliced at all (every pack_* function below keys on that), else one flag per document.
 static constexpr uint64_t kDvbRawBit = 0x8000;
 static inline uint32_t dvb_gap_limit(uint64_t i) { return (i & 7) <= 3 ? 4096u : 2048u; }   // element i of its slice (i & 7 != 0)
-void pack_dvb_raw_flags(const HostIndex& h, std::vector<uint8_t>* out) {
+void pack_dvb_raw_flags(const HostIndex& h, bool f16_slices, std::vector<uint8_t>* out) {
   std::vector<uint8_t>& raw = *out;
-  raw.assign(h.value_type == SGPU_VAL_DOTVBYTE ? h.n_docs : 0, 0);
+  const bool sliced = h.value_type == SGPU_VAL_DOTVBYTE || (f16_slices && pack_f16_slices_possible(h));
+  raw.assign(sliced ? h.n_docs : 0, 0);
   if (raw.empty()) return;
   const uint16_t* comps = (const uint16_t*)h.fwd_comps.data();
 #pragma omp parallel for schedule(static) num_threads(sgpu::host_threads())
   for (int64_t doc = 0; doc < (int64_t)h.n_docs; ++doc) {
     const uint64_t s0 = h.fwd_offsets[(size_t)doc], s1 = h.fwd_offsets[(size_t)doc + 1];
-    uint8_t r = 0;
+    uint8_t r = s1 - s0 > 32767 ? 1 : 0;   // (the raw flag takes bit 15 of the length field; an f16 document that long is stored raw - and cannot be: see pack_f16_slices_possible)
     for (uint64_t i = s0 + 1; i < s1; ++i)
       if (((i - s0) & 7) != 0 && (uint32_t)comps[i] - (uint32_t)comps[i - 1] >= dvb_gap_limit(i - s0)) r = 1;
     raw[(size_t)doc] = r;
   }
 }
+// An f16 index can take the sliced layout when its components are u16 and no document has more than 32767 of them (the
+// raw flag lives in bit 15 of a ref's length field).
+bool pack_f16_slices_possible(const HostIndex& h) {
+  if (h.value_type != SGPU_VAL_F16 || h.comp_width != 2) return false;
+  for (uint64_t d = 0; d < h.n_docs; ++d)
+    if (h.fwd_offsets[d + 1] - h.fwd_offsets[d] > 32767) return false;
+  return true;
+}
 // bytes of a document's record (before the padding to 16)
 static inline uint64_t record_bytes(const HostIndex& h, const std::vector<uint8_t>& raw, uint64_t doc, uint64_t len) {
   const uint64_t npad = (len + 7) & ~7ull;
-  if (h.value_type == SGPU_VAL_DOTVBYTE && !raw[doc]) {
-    const uint64_t ns = npad / 8;
-    return ((ns * 12 + 7) & ~7ull) + ns * 8;   // [ns x 12 B gaps][pad to 8][ns x 8 B codes]
+  if (!raw.empty() && !raw[doc]) {
+    const uint64_t ns = npad / 8, vb8 = 8ull * h.val_bytes();   // [ns x 12 B gaps][pad to the values' 8 / 16 B][ns x 8 values]
+    return ((ns * 12 + vb8 - 1) & ~(vb8 - 1)) + ns * vb8;
   }
   return npad * (h.comp_width + h.val_bytes());
 }
 static inline uint64_t ref_len_field(const HostIndex& h, const std::vector<uint8_t>& raw, uint64_t doc, uint64_t len) {
-  return len | ((h.value_type == SGPU_VAL_DOTVBYTE && raw[doc]) ? kDvbRawBit : 0ull);
+  return len | ((!raw.empty() && raw[doc]) ? kDvbRawBit : 0ull);
 }
 
 // Record offsets in 16-byte units. A record is moved to the next `line16`-unit line only if it would
@@ -71,13 +82,14 @@ void pack_records(const HostIndex& h, const std::vector<uint8_t>& raw, const std
     const uint64_t s0 = h.fwd_offsets[(size_t)doc], len = h.fwd_offsets[(size_t)doc + 1] - s0;
     const uint64_t npad = (len + 7) & ~7ull;
     uint8_t* rec = fwd.data() + rec_off16[(size_t)doc] * 16;
-    if (h.value_type == SGPU_VAL_DOTVBYTE && !raw[(size_t)doc]) {
+    if (!raw.empty() && !raw[(size_t)doc]) {
       // per slice three dwords = 96 bits: [0,16) first component | [16,28) [28,40) [40,52) gaps of elements 1 .. 3 |
       // [52,63) [63,74) [74,85) [85,96) gaps of elements 4 .. 7; padding elements: gap 0, code 0
       const uint16_t* comps = (const uint16_t*)h.fwd_comps.data() + s0;
       const uint64_t ns = npad / 8;
       uint32_t* gw = (uint32_t*)rec;
-      uint8_t* codes = rec + ((ns * 12 + 7) & ~7ull);
+      const uint64_t vb8 = 8ull * vb;
+      uint8_t* codes = rec + ((ns * 12 + vb8 - 1) & ~(vb8 - 1));   // (the values: u8 codes, or binary16 for the sliced f16 layout)
       for (uint64_t sl = 0; sl < ns; ++sl) {
         uint32_t g[8];
         g[0] = comps[sl * 8];
@@ -89,7 +101,8 @@ void pack_records(const HostIndex& h, const std::vector<uint8_t>& raw, const std
         gw[3 * sl + 1] = (g[2] >> 4) | (g[3] << 8) | (g[4] << 20) | (g[5] << 31);
         gw[3 * sl + 2] = (g[5] >> 1) | (g[6] << 10) | (g[7] << 21);
       }
-      std::memcpy(codes, h.fwd_codes.data() + s0, len);
+      if (vb == 2) std::memcpy(codes, h.fwd_vals.data() + s0, len * 2);
+      else std::memcpy(codes, h.fwd_codes.data() + s0, len);
       continue;
     }
     std::memcpy(rec, h.fwd_comps.data() + s0 * cw, len * cw);

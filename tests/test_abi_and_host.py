@@ -532,6 +532,32 @@ def test_dotvbyte_records_decode_to_their_documents(tmp_path):
     assert back.desc.value_type == 2 and np.array_equal(orc.desc_arrays(back.desc)["fwd_vals"], a2["fwd_vals"])
     again = dvb.convert(1)   # (kept alive: desc_arrays views the index's own memory)
     assert again.desc.value_type == 1 and np.array_equal(orc.desc_arrays(again.desc)["fwd_vals"], a1["fwd_vals"])
+    # the f16 index itself takes the same component stream in front of its binary16 values (r05: the sliced internal
+    # layout chosen at upload; SGPU_FWD_STREAM=plain keeps the [components | values] records): every record decodes to
+    # its document with the SAME raw / packed decision per document, and the store is smaller than the plain one
+    need_s, need_p = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    os.environ["SGPU_FWD_STREAM"] = "plain"
+    try:
+        assert L.sgpu_debug_pack_forward(f16.h, None, 0, None, ctypes.byref(need_p)) == 0
+    finally:
+        del os.environ["SGPU_FWD_STREAM"]
+    assert L.sgpu_debug_pack_forward(f16.h, None, 0, None, ctypes.byref(need_s)) == 0
+    assert need_s.value < need_p.value
+    fwd_s = np.zeros(need_s.value + 16, np.uint8)
+    refs_s = np.zeros(d.n_docs, np.uint64)
+    assert L.sgpu_debug_pack_forward(f16.h, fwd_s.ctypes.data_as(ctypes.c_void_p), need_s.value, refs_s.ctypes.data_as(ctypes.c_void_p),
+                                     ctypes.byref(need_s)) == 0
+    O.orc_slices_decode_record.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    af = orc.desc_arrays(f16.desc)
+    for doc in range(int(d.n_docs)):
+        ref, ref_d = int(refs_s[doc]), int(refs[doc])
+        ln, raw, off16 = ref & 0x7fff, (ref >> 15) & 1, ref >> 16
+        assert (ln, raw) == (ref_d & 0x7fff, (ref_d >> 15) & 1), doc     # same length, same raw / packed decision as the DotVByte index
+        s, e = int(fo[doc]), int(fo[doc + 1])
+        co, vo = np.zeros(max(ln, 1), np.uint16), np.zeros(max(ln, 1), np.uint16)
+        rc = O.orc_slices_decode_record(fwd_s.ctypes.data + off16 * 16, ln, raw, 2, co.ctypes.data_as(ctypes.c_void_p), vo.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, (doc, rc)
+        assert np.array_equal(co[:ln], af["fwd_comps"][s:e]) and np.array_equal(vo[:ln], af["fwd_vals"][s:e].view(np.uint16)), doc
     # u32 components have no DotVByte form (the reference's class is u16-only)
     w = _native.NativeIndex.build(4, 70000, *random_dataset(3, 50, 70000))
     with pytest.raises(_native.SeismicHipError) as ei:

@@ -1,7 +1,7 @@
-"""Kernel time of mid-size launches (256 ... 2500 queries) on the 8.8M-document shape; SGPU_COOP* knobs are honoured."""
+"""Kernel time of mid-size launches (256 ... 2500 queries, or the sizes given) on the 8.8M-document shape; SGPU_COOP* knobs are honoured."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from seismic_amd import _native
 n=8800000
 docs = _native.synth(n, 30000, 42, 0)
@@ -16,7 +16,8 @@ else:
 ix.upload(0)
 NQ=5000
 q_off, qc, qv = _native.synth(NQ, 30000, 43, 1, docs)
-for nq in (256, 1000, 1250, 2500):
+SIZES = [int(x) for x in sys.argv[1:]] or [256, 1000, 1250, 2500]
+for nq in SIZES:
     bs=[]
     for r in range(NQ//nq):
         lo,hi=r*nq,(r+1)*nq
