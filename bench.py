@@ -60,6 +60,10 @@ def parse_args():
     ap.add_argument("--docs", type=int, default=8_800_000)
     ap.add_argument("--dim", type=int, default=30_000)
     ap.add_argument("--queries", type=int, default=10_000, help="queries per step (one batch)")
+    ap.add_argument("--collection", choices=["survey", "clustered"], default="survey",
+                    help="synthetic collection: `survey` = the SURVEY 8(d) law (the headline); `clustered` = same sizes, documents "
+                         "drawn around latent intents and queries carrying their source document's weights (synth.cpp): work "
+                         "per query and recall at the reference's parameters in the range published for MS MARCO")
     ap.add_argument("--batches", type=int, default=0,
                     help="distinct resident batches (0 = one per step incl. warm-up, at most 64)")
     ap.add_argument("--scaling", choices=["auto", "strong", "weak"], default="auto")
@@ -118,6 +122,8 @@ def parse_args():
 
 def workload_key(args, world, scaling):
     src = "docs=%d dim=%d" % (args.docs, args.dim) if not args.documents else "documents=%s" % os.path.basename(args.documents)
+    if args.collection != "survey" and not args.documents:
+        src += " collection=" + args.collection
     key = "%s queries=%d k=%d query_cut=%d heap_factor=%s first_sorted=%d cw=%d np=%d cf=%g se=%g mf=%g" % (
         src, args.queries, args.k, args.query_cut, args.heap_factor, args.first_sorted, args.comp_width,
         args.n_postings, args.centroid_fraction, args.summary_energy, args.max_fraction)
@@ -246,7 +252,8 @@ def main():
                                summary_energy=args.summary_energy, max_fraction=args.max_fraction,
                                min_cluster_size=args.min_cluster_size, doc_cut=15,
                                use_device=0 if args.build_on_host else (local_rank + 1))
-    src_tag = ("%d_%d" % (args.docs, args.dim)) if not args.documents else \
+    coll = 1 if args.collection == "clustered" else 0
+    src_tag = ("%d_%d%s" % (args.docs, args.dim, "_clu" if coll else "")) if not args.documents else \
         ("file_%s_%d" % (os.path.basename(args.documents), os.path.getsize(args.documents)))
     tag = "sgpu2_%s_cw%d_np%d_cf%g_se%g_mf%g_mc%d" % (
         src_tag, args.comp_width, args.n_postings, args.centroid_fraction, args.summary_energy,
@@ -273,7 +280,7 @@ def main():
         docs = None
         if need_docs:
             t0 = time.time()
-            docs = _native.read_inner_format(args.documents) if args.documents else _native.synth(args.docs, args.dim, 42, 0)
+            docs = _native.read_inner_format(args.documents) if args.documents else _native.synth(args.docs, args.dim, 42, 0, collection=coll)
             t_gen = time.time() - t0
         wrote = True
         if index is None:
@@ -296,7 +303,7 @@ def main():
         if args.queries_file:
             allq = _native.read_inner_format(args.queries_file)
         else:
-            allq = _native.synth(args.queries * n_sets, int(index.desc.dim), 43, 1, docs)
+            allq = _native.synth(args.queries * n_sets, int(index.desc.dim), 43, 1, docs, collection=coll)
         if write_files and world > 1 and wrote:
             tmp = "%s.tmp.%d" % (qpath, os.getpid())
             try:
@@ -472,7 +479,7 @@ def main():
         "config": {
             "workload": ("%s: %d docs, %d vocab, ~%d nnz/doc, best_configs params, "
                          "k=%d, %d-query batch per step%s, %d distinct batches, %s"
-                         % ("MSMARCO-passage SPLADE-v3 shape (synthetic)" if not args.documents
+                         % (("MSMARCO-passage SPLADE-v3 shape (synthetic%s)" % (", clustered collection" if coll else "")) if not args.documents
                             else "documents %s" % os.path.basename(args.documents),
                             int(d.n_docs), int(d.dim), int(d.nnz) // max(int(d.n_docs), 1), args.k, args.queries,
                             (" sharded over %d GPUs" % world) if (world > 1 and scaling == "strong") else
@@ -719,7 +726,7 @@ def main():
                     v_[0].close()
                 built.clear()
                 t1 = time.time()
-                docs_ = _native.read_inner_format(args.documents) if args.documents else _native.synth(args.docs, args.dim, 42, 0)
+                docs_ = _native.read_inner_format(args.documents) if args.documents else _native.synth(args.docs, args.dim, 42, 0, collection=coll)
                 cfg_ = BuildConfig.defaults(n_postings=int(ip["n_postings"]), centroid_fraction=float(ip["centroid_fraction"]),
                                             summary_energy=float(ip["summary_energy"]), max_fraction=float(ip["max_fraction"]),
                                             min_cluster_size=args.min_cluster_size, doc_cut=15,
@@ -746,7 +753,7 @@ def main():
                 return float(ms_), recall_of(pid_, pn_), (recall_of(pid_, pn_, ns, ns + nh) if nh else None)
 
             # the recorded points belong to the collection they were swept on
-            rec_applies = (not args.documents and recorded.get("docs") == args.docs and recorded.get("dim") == args.dim
+            rec_applies = (not args.documents and coll == 0 and recorded.get("docs") == args.docs and recorded.get("dim") == args.dim
                            and args.comp_width == 2)
             for tgt in targets:
                 rec = rec_by_t.get(round(tgt, 4)) if rec_applies else None

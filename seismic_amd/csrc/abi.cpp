@@ -515,13 +515,31 @@ sgpu_status sgpu_search_sequential(sgpu_index* idx, const uint64_t* q_off, const
                                       breakdown_us, nullptr);
 }
 
-// (not part of the boundary: the team size a host-parallel phase would take for num_threads == 0)
-uint32_t sgpu_debug_host_threads(void) { return (uint32_t)host_threads(); }
+// ---- test hooks (include/seismic_hip_testing.h; NOT part of the boundary) ---------------------------------------
+// Entry points the test suite and the tools use to look at host-side decisions (team size, chunk plan, launch plan,
+// packed records, phase clocks, cooperative trace). Like the undocumented environment names they are inert unless
+// SGPU_TEST_HOOKS=1 is set: status-returning ones fail with SGPU_EINVAL, the others return 0 / do nothing.
+static bool test_hooks_on() {
+  const char* t = std::getenv("SGPU_TEST_HOOKS");
+  return t && *t && *t != '0';
+}
+#define SGPU_HOOK_OR(ret)                                                                            \
+  if (!test_hooks_on()) {                                                                            \
+    (void)fail(SGPU_EINVAL, "%s is a test hook: set SGPU_TEST_HOOKS=1 (include/seismic_hip_testing.h)", __func__); \
+    return ret;                                                                                      \
+  }
+
+// (the team size a host-parallel phase would take for num_threads == 0)
+uint32_t sgpu_debug_host_threads(void) {
+  SGPU_HOOK_OR(0u);
+  return (uint32_t)host_threads();
+}
 
 // (not part of the boundary: how search_shard would cut a call of nq queries when `lanes_free` lanes can be had -
 // bounds[2 * j], bounds[2 * j + 1] = the queries [q0, q1) of launch j; returns the number of launches)
 uint32_t sgpu_debug_chunk_plan(uint32_t nq, uint32_t chunk_min, uint32_t chunk_max, uint32_t want_tail, uint32_t coop_max,
                                uint32_t lanes_free, uint32_t* bounds) {
+  SGPU_HOOK_OR(0u);
   uint32_t tail = 0;
   uint32_t n_jobs = chunk_jobs(nq, chunk_min, chunk_max < 1 ? 1 : (chunk_max > 8 ? 8 : chunk_max), want_tail, coop_max, &tail);
   if (lanes_free >= 1 && n_jobs > lanes_free) n_jobs = lanes_free;
@@ -534,13 +552,14 @@ uint32_t sgpu_debug_chunk_plan(uint32_t nq, uint32_t chunk_min, uint32_t chunk_m
 // of every document, (record offset / 16) << 16 | length field; out_fwd == null: *out_bytes = the size needed.
 // tests/test_abi_and_host.py decodes every record with the oracle's restatement of the layout.)
 sgpu_status sgpu_debug_pack_forward(const sgpu_index* idx, uint8_t* out_fwd, uint64_t cap, uint64_t* out_doc_ref, uint64_t* out_bytes) {
+  SGPU_HOOK_OR(SGPU_EINVAL);
   if (!idx || !out_bytes) return fail(SGPU_EINVAL, "null argument");
   try {
     std::vector<uint8_t> raw, fwd;
     std::vector<uint64_t> off16, dref;
-    {   // (an f16 index: the layout sgpu_index_upload would choose - sliced unless SGPU_FWD_STREAM=plain)
+    {   // (an f16 index: the layout sgpu_index_upload would choose - plain unless SGPU_FWD_STREAM=sliced)
       const char* fs = std::getenv("SGPU_FWD_STREAM");
-      pack_dvb_raw_flags(idx->host, !(fs && std::string(fs) == "plain"), &raw);
+      pack_dvb_raw_flags(idx->host, fs && std::string(fs) == "sliced", &raw);
     }
     pack_record_offsets(idx->host, raw, 128 / 16, &off16);
     *out_bytes = std::max<uint64_t>(off16[idx->host.n_docs] * 16, 16);
@@ -560,16 +579,21 @@ sgpu_status sgpu_debug_pack_forward(const sgpu_index* idx, uint8_t* out_fwd, uin
 // query needs at most, largest list walked first, largest list walked}; needs no device)
 sgpu_status sgpu_debug_plan(const sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals, uint32_t nq,
                             uint32_t query_cut, uint32_t* order_out, uint32_t* out3) {
+  SGPU_HOOK_OR(SGPU_EINVAL);
   if (!idx || !q_off || !order_out || !out3) return fail(SGPU_EINVAL, "null argument");
   return debug_plan(idx->host, q_off, comps, vals, nq, query_cut, order_out, out3);
 }
 
 // (not part of the boundary: the calling thread's staged calls add the wall time of their host-side phases to
 // buf[0..7] from now on - see device_index.hip: call_timing; null switches it off. tools/shard_probe.py)
-void sgpu_debug_call_timing(double* buf8) { call_timing() = buf8; }
+void sgpu_debug_call_timing(double* buf8) {
+  SGPU_HOOK_OR();
+  call_timing() = buf8;
+}
 
 // (not part of the boundary: the timeline of a cooperative launch, for tools/coop_trace.py on a trace build)
 uint32_t sgpu_debug_coop_trace(sgpu_index* idx, uint64_t* out, uint32_t cap) {
+  SGPU_HOOK_OR(0u);
   return idx ? coop_trace_dump(idx->dev, out, cap) : 0;
 }
 

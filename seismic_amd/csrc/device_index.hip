@@ -28,15 +28,21 @@ hipError_t run_u32_packed_u8(const LaunchArgs& a, int* occupancy);
 hipError_t run_u32_split_u8(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_dense_dvb(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_packed_dvb(const LaunchArgs& a, int* occupancy);
+#ifdef SGPU_WITH_F16S   // (make WITH_F16S=1: the sliced layout of an f16 index - measured slower than the plain records, off by default)
 hipError_t run_u16_dense_f16s(const LaunchArgs& a, int* occupancy);
 hipError_t run_u16_packed_f16s(const LaunchArgs& a, int* occupancy);
+#endif
 
 static hipError_t run_any(const LaunchArgs& a, int* occ) {
   // (u16 components: dense byte table or packed {bits, rank} words. The hashed lookup is the u32 layout: for u16 it
   // measured slower than both - 6.46 against 5.81 ms per 10 000-query launch, profiles/r03_lds_sensitivity.md - and its
   // three families were dropped in r05)
   if (a.comp_width == 2 && a.lookup != LK_DENSE && a.lookup != LK_PACKED) return hipErrorInvalidConfiguration;
+#ifdef SGPU_WITH_F16S
   if (a.value_type == kDevValF16Sliced) return a.lookup == LK_DENSE ? run_u16_dense_f16s(a, occ) : run_u16_packed_f16s(a, occ);
+#else
+  if (a.value_type == kDevValF16Sliced) return hipErrorInvalidConfiguration;
+#endif
   if (a.value_type == SGPU_VAL_DOTVBYTE)   // (u16 components only)
     return a.lookup == LK_DENSE ? run_u16_dense_dvb(a, occ) : run_u16_packed_dvb(a, occ);
   if (a.value_type == SGPU_VAL_FIXEDU8 && a.comp_width == 4) return a.lookup == LK_SPLIT ? run_u32_split_u8(a, occ) : run_u32_packed_u8(a, occ);
@@ -286,12 +292,17 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     // ~4.75 lines, line-fitted 4.
     std::vector<uint64_t> rec_off16;
     std::vector<uint8_t> dvb_raw;   // sliced layouts: the documents that keep the raw record form (a gap too wide for its field)
-    // An f16 index over u16 components takes the SLICED layout (r05: the DotVByte index's compressed component stream in
-    // front of the binary16 values, 28 bytes per 8-element slice instead of 32; lossless, rows bit-identical; kernel
-    // VT_F16S) unless SGPU_FWD_STREAM=plain asks for the [components | values] records of r01 - r04.
+    // SGPU_FWD_STREAM=sliced (libraries built with `make WITH_F16S=1` only): an f16 index over u16 components takes the
+    // SLICED layout - the DotVByte index's compressed component stream in front of the binary16 values, 28 bytes per
+    // 8-element slice instead of 32; lossless, rows bit-identical (kernel VT_F16S). Measured r05 on the 8.8M-document
+    // collection: 33.0 GB resident instead of 36.3 and 6.02 ms per 10 000-query launch instead of 5.94 - the decode costs
+    // more than the bytes return (profiles/r05_bytes_experiments.md); a footprint option, not in the default build.
     {
       const char* fs = std::getenv("SGPU_FWD_STREAM");
-      const bool want = !(fs && std::strcmp(fs, "plain") == 0);
+      const bool want = fs && std::strcmp(fs, "sliced") == 0;
+#ifndef SGPU_WITH_F16S
+      if (want) return bail(fail(SGPU_EINVAL, "SGPU_FWD_STREAM=sliced needs a library built with `make WITH_F16S=1`"));
+#endif
       pack_dvb_raw_flags(h, want, &dvb_raw);
       d->fwd_sliced = h.value_type == SGPU_VAL_F16 && !dvb_raw.empty();
     }
@@ -754,6 +765,13 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
     pl.query_cut = query_cut;
     std::vector<std::pair<uint64_t, uint32_t>> cost(nq);
     uint32_t max_nb = 0, dots_cap = 1, max_list_nb = 1;
+    // (test hook SGPU_AFFINITY_CLASSES = n > 0, the bytes experiment of r04 / r05: inside each of n cost classes of the
+    // longest-first order, queries that walk the same FIRST list are queued next to each other - they then run at the
+    // same time on different workgroups and can meet each other's summary rows and records in L2 / the Infinity Cache.
+    // Measured with counters in r05, profiles/r05_bytes_experiments.md: no effect on traffic or time; off.)
+    const uint32_t aff_classes = nq >= 4096 ? hook_u32("SGPU_AFFINITY_CLASSES", 0) : 0;
+    std::vector<uint32_t> first_list;
+    if (aff_classes) first_list.resize(nq);
     {   // serial on purpose (an OpenMP team costs more to wake than this takes): ~60 ns per query for query_cut <= 16
       constexpr uint32_t kSmall = 16;
       std::vector<std::pair<int32_t, uint32_t>> kv;   // (large query_cut only)
@@ -800,6 +818,7 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
         }
         const uint32_t c0 = nl ? (query_cut <= kSmall ? sel[0] : kv[0].second) : 0xffffffffu;
         if (nl) max_nb = std::max(max_nb, d->list_nb[c0]);
+        if (!first_list.empty()) first_list[(size_t)q] = c0;
         dots_cap = std::max(dots_cap, nb);
         cost[(size_t)q] = {np, (uint32_t)q};
       }
@@ -811,9 +830,14 @@ static sgpu_status make_plan(const DeviceIndex* d, const uint64_t* h_off, const 
     std::sort(cost.begin(), cost.end(), [](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) {
       return a.first != c.first ? a.first > c.first : a.second < c.second;
     });
-    // (measured r04 and dropped: queueing queries that walk the same first list next to each other inside 16 / 64 /
-    // 256 cost classes, so that they meet each other's lines in the Infinity Cache: 5.94 ms per 10 000-query launch
-    // without, 5.95 / 5.98 / 5.91 with - noise)
+    if (aff_classes) {
+      const size_t per = ((size_t)nq + aff_classes - 1) / aff_classes;
+      for (size_t c0 = 0; c0 < nq; c0 += per)
+        std::stable_sort(cost.begin() + (long)c0, cost.begin() + (long)std::min<size_t>(nq, c0 + per),
+                         [&](const std::pair<uint64_t, uint32_t>& a, const std::pair<uint64_t, uint32_t>& c) {
+                           return first_list[a.second] < first_list[c.second];
+                         });
+    }
     pl.order.resize(2 * (size_t)nq);
     for (uint32_t i = 0; i < nq; ++i) pl.order[i] = cost[i].second;
     // LK_HASH seeds: the first multiplier of the family that sends the query's components to distinct slots

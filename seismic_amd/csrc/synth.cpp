@@ -16,7 +16,7 @@
 //
 // Second collection (sgpu_synth_spec::collection == 1, "clustered"; bench.py --collection clustered): same sizes, same
 // PRNG discipline, but documents are drawn around LATENT INTENTS the way passages about one subject are: the
-// collection is cut into groups of ~kGroupDocs documents; a group belongs to a topic and owns a core of kCoreTokens
+// collection is cut into groups of ~96 documents; a group belongs to a topic and owns a core of kCoreTokens
 // of the topic's tokens with a weight each; a document takes most of its group's core (80 % of the tokens, weight x
 // lognormal noise), a fifth of its tokens from the rest of its topic and the remainder from the Zipf law. A query
 // repeats the heaviest components of its source document WITH that document's weights (x noise), so its exact
@@ -26,6 +26,8 @@
 // kernel's figures survive on work per query of the published size.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -68,8 +70,30 @@ inline float value_law(SplitMix64& rng, double scale) {
 }
 
 constexpr uint32_t kTopicTokens = 256;
-constexpr uint32_t kGroupDocs = 96;     // clustered collection: documents per latent intent (mean)
-constexpr uint32_t kCoreTokens = 48;    //   tokens of a group's core
+constexpr uint32_t kCoreTokens = 48;    // clustered collection: tokens of a group's core
+// ... and its law's parameters: documents per latent intent (mean), share of the core a document takes, sigma of the
+// lognormal noise on a document's core weights and on the weights a query repeats from its source document.
+// (SGPU_SYNTH_CLUSTER="group,take,doc_sigma,query_sigma" overrides them while SGPU_TEST_HOOKS=1 is set: tools/clustered_tune.py)
+struct ClusterLaw {
+  uint32_t group_docs = 96;
+  double take = 0.8, doc_sigma = 0.25, query_sigma = 0.3;
+};
+static ClusterLaw cluster_law() {
+  ClusterLaw l;
+  const char* t = std::getenv("SGPU_TEST_HOOKS");
+  const char* v = (t && *t && *t != '0') ? std::getenv("SGPU_SYNTH_CLUSTER") : nullptr;
+  if (v) {
+    unsigned g = 0;
+    double a = 0, b = 0, c = 0;
+    if (std::sscanf(v, "%u,%lf,%lf,%lf", &g, &a, &b, &c) == 4 && g >= 1) {
+      l.group_docs = g;
+      l.take = a;
+      l.doc_sigma = b;
+      l.query_sigma = c;
+    }
+  }
+  return l;
+}
 
 }  // namespace
 
@@ -139,8 +163,8 @@ static GroupCore group_core(uint64_t dim, uint64_t g, uint32_t n_topics, const s
   }
   return gc;
 }
-static inline uint64_t group_of(uint64_t doc, uint64_t n_docs) {   // documents are dealt to groups by a hash: no id locality
-  const uint64_t n_groups = std::max<uint64_t>(1, n_docs / kGroupDocs);
+static inline uint64_t group_of(uint64_t doc, uint64_t n_docs, uint32_t group_docs) {   // documents are dealt to groups by a hash: no id locality
+  const uint64_t n_groups = std::max<uint64_t>(1, n_docs / group_docs);
   return mix_seed(0x6209ull, doc) % n_groups;
 }
 
@@ -168,6 +192,7 @@ extern "C" sgpu_status sgpu_synth_generate(const sgpu_synth_spec* spec, const ui
   if (!write) return SGPU_OK;
   std::copy(off.begin(), off.end(), out_offsets);
 
+  const ClusterLaw law = cluster_law();
   Zipf z(dim, 0xd1ce);
   const uint32_t n_topics = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(4096, dim / 64));
   std::vector<uint32_t> ttok;
@@ -188,10 +213,10 @@ extern "C" sgpu_status sgpu_synth_generate(const sgpu_synth_spec* spec, const ui
       cur.clear();
       if (spec->kind == 0 && spec->collection == 1) {
         // clustered: most of the group's core (weights x lognormal noise), a fifth from the rest of the topic, then Zipf
-        const GroupCore gc = group_core(dim, group_of(i, spec->n_vecs), n_topics, tscale);
+        const GroupCore gc = group_core(dim, group_of(i, spec->n_vecs, law.group_docs), n_topics, tscale);
         for (uint32_t j = 0; j < kCoreTokens && cur.size() < n; ++j) {
-          const bool take = rng.unit() < 0.8;
-          const double noise = std::exp(0.25 * normal(rng));
+          const bool take = rng.unit() < law.take;
+          const double noise = std::exp(law.doc_sigma * normal(rng));
           const uint32_t c = ttok[(size_t)gc.topic * kTopicTokens + gc.slot[j]];
           if (!take || used[c]) continue;
           used[c] = 1;
@@ -239,7 +264,7 @@ extern "C" sgpu_status sgpu_synth_generate(const sgpu_synth_spec* spec, const ui
         for (uint32_t j = 0; j < n_src; ++j) {
           used[sv[j].second] = 1;
           // (clustered: the source document's own weight x noise - the query is ABOUT that document)
-          const float v = spec->collection == 1 ? (float)std::min(3.5, std::max(0.02, (double)(-sv[j].first) * std::exp(0.3 * normal(rng))))
+          const float v = spec->collection == 1 ? (float)std::min(3.5, std::max(0.02, (double)(-sv[j].first) * std::exp(law.query_sigma * normal(rng))))
                                                 : value_law(rng, 1.0);
           cur.emplace_back(sv[j].second, v);
         }

@@ -19,13 +19,27 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def test_every_declared_symbol_is_exported():
-    hdr = open(os.path.join(ROOT, "include", "seismic_hip.h")).read()
-    names = set(re.findall(r"\b(sgpu_[a-z_0-9]+)\s*\(", hdr))
-    assert len(names) >= 20
     L = ctypes.CDLL(_native.LIB_PATH)
-    missing = [n for n in sorted(names) if not hasattr(L, n)]
-    assert not missing, missing
+    for header, at_least in (("seismic_hip.h", 20), ("seismic_hip_testing.h", 6)):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        names = set(re.findall(r"\b(sgpu_[a-z_0-9]+)\s*\(", hdr))
+        assert len(names) >= at_least, header
+        missing = [n for n in sorted(names) if not hasattr(L, n)]
+        assert not missing, (header, missing)
     assert L.sgpu_abi_version() == 4
+
+
+def test_test_hooks_are_inert_without_the_switch(monkeypatch):
+    """The sgpu_debug_* entry points (include/seismic_hip_testing.h) and the undocumented environment names only work
+    while SGPU_TEST_HOOKS=1 is set - the suite's conftest sets it; a deployment does not."""
+    L = ctypes.CDLL(_native.LIB_PATH)
+    L.sgpu_debug_host_threads.restype = ctypes.c_uint32
+    assert L.sgpu_debug_host_threads() >= 1
+    monkeypatch.delenv("SGPU_TEST_HOOKS")
+    assert L.sgpu_debug_host_threads() == 0
+    need = ctypes.c_uint64(0)
+    assert L.sgpu_debug_pack_forward(None, None, 0, None, ctypes.byref(need)) == 1   # SGPU_EINVAL: "is a test hook"
+    assert b"test hook" in ctypes.cast(L.sgpu_last_error, ctypes.CFUNCTYPE(ctypes.c_char_p))()
 
 
 def test_struct_layouts_match_header_sizes():
@@ -532,21 +546,21 @@ def test_dotvbyte_records_decode_to_their_documents(tmp_path):
     assert back.desc.value_type == 2 and np.array_equal(orc.desc_arrays(back.desc)["fwd_vals"], a2["fwd_vals"])
     again = dvb.convert(1)   # (kept alive: desc_arrays views the index's own memory)
     assert again.desc.value_type == 1 and np.array_equal(orc.desc_arrays(again.desc)["fwd_vals"], a1["fwd_vals"])
-    # the f16 index itself takes the same component stream in front of its binary16 values (r05: the sliced internal
-    # layout chosen at upload; SGPU_FWD_STREAM=plain keeps the [components | values] records): every record decodes to
+    # the f16 index itself can take the same component stream in front of its binary16 values (r05: the sliced internal
+    # layout, SGPU_FWD_STREAM=sliced in libraries built WITH_F16S=1; the host-side packing is always there): every record decodes to
     # its document with the SAME raw / packed decision per document, and the store is smaller than the plain one
     need_s, need_p = ctypes.c_uint64(0), ctypes.c_uint64(0)
-    os.environ["SGPU_FWD_STREAM"] = "plain"
+    assert L.sgpu_debug_pack_forward(f16.h, None, 0, None, ctypes.byref(need_p)) == 0
+    os.environ["SGPU_FWD_STREAM"] = "sliced"
     try:
-        assert L.sgpu_debug_pack_forward(f16.h, None, 0, None, ctypes.byref(need_p)) == 0
+        assert L.sgpu_debug_pack_forward(f16.h, None, 0, None, ctypes.byref(need_s)) == 0
+        assert need_s.value < need_p.value
+        fwd_s = np.zeros(need_s.value + 16, np.uint8)
+        refs_s = np.zeros(d.n_docs, np.uint64)
+        assert L.sgpu_debug_pack_forward(f16.h, fwd_s.ctypes.data_as(ctypes.c_void_p), need_s.value, refs_s.ctypes.data_as(ctypes.c_void_p),
+                                         ctypes.byref(need_s)) == 0
     finally:
         del os.environ["SGPU_FWD_STREAM"]
-    assert L.sgpu_debug_pack_forward(f16.h, None, 0, None, ctypes.byref(need_s)) == 0
-    assert need_s.value < need_p.value
-    fwd_s = np.zeros(need_s.value + 16, np.uint8)
-    refs_s = np.zeros(d.n_docs, np.uint64)
-    assert L.sgpu_debug_pack_forward(f16.h, fwd_s.ctypes.data_as(ctypes.c_void_p), need_s.value, refs_s.ctypes.data_as(ctypes.c_void_p),
-                                     ctypes.byref(need_s)) == 0
     O.orc_slices_decode_record.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
     af = orc.desc_arrays(f16.desc)
     for doc in range(int(d.n_docs)):
