@@ -1014,7 +1014,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   const uint64_t budget = hook_u32("SGPU_LDS_TARGET", 160u * 1024u / 2u);   // 2 workgroups per CU
   // query lookup table: dense u8 index (1 B per vocabulary id + the padding sentinel) when it is
   // allowed and fits at 2 workgroups per CU, else {bits, rank} per 32 vocabulary ids
-  const uint64_t dense_bytes = up((uint64_t)d->view.dim + 1), bitmap_bytes = up((uint64_t)words * 8);
+  const uint64_t dense_bytes = std::max<uint64_t>(up((uint64_t)d->view.dim + 1), hook_u32("SGPU_DENSE_BYTES", 0)), bitmap_bytes = up((uint64_t)words * 8);
   const bool dense_ok = d->comp_width == 2 && d->view.dim <= 65535 && b->max_nnz <= 255 &&
                         !hook_u32("SGPU_NO_DENSE", 0) && searching;
   const uint64_t split_bits = up((uint64_t)words * 4), split_bytes = split_bits + up((uint64_t)words * 2);

@@ -47,6 +47,12 @@ def test_two_ranks_strong_scaling_is_the_single_gpu_answer(tmp_path):
     w = out["replicas_weak_scaling"]
     assert w["queries_per_gpu_per_step"] == 1501 and w["value"] > 0 and w["ms_per_step"] > 0
     assert "single_gpu_legs" in out and "end_to_end" not in out
+    # what `value` measured is said in the line, and the literal reading of BASELINE configs[3] stands next to it:
+    # one batch at a time (a barrier around every step, one call per rank)
+    assert "pipelined" in out["value_is"]
+    assert out["value_one_batch_at_a_time"] > 0 and out["one_batch_at_a_time"]["ms_per_step"] > 0
+    assert out["value_one_batch_at_a_time"] <= out["value"] * 1.5   # (never far above the pipelined figure)
+    assert int(out["host_threads_per_rank_for_host_phases"]) >= 1
 
 
 def test_two_ranks_weak_scaling(tmp_path):

@@ -33,10 +33,11 @@ ap.add_argument("--summary-energy", type=float, default=0.5)
 ap.add_argument("--max-fraction", type=float, default=6.0)
 ap.add_argument("--min-cluster-size", type=int, default=2)
 ap.add_argument("--no-save", action="store_true", help="do not cache the built index under /tmp")
+ap.add_argument("--collection", type=int, default=0, help="0 = SURVEY 8(d) law, 1 = clustered")
 a = ap.parse_args()
 npost = a.n_postings or max(1, 2000 * a.docs // 1000000)
-docs = _native.synth(a.docs, a.dim, 42, 0)
-path = "/tmp/prof_%d_%d_%d_cw%d_cf%g.idx" % (a.docs, a.dim, npost, a.comp_width, a.centroid_fraction)
+docs = _native.synth(a.docs, a.dim, 42, 0, collection=a.collection)
+path = "/tmp/prof_%d_%d_%d_cw%d_cf%g_c%d.idx" % (a.docs, a.dim, npost, a.comp_width, a.centroid_fraction, a.collection)
 if os.path.exists(path) and not a.no_save:
     ix = _native.NativeIndex.load(path)
 else:
@@ -48,7 +49,7 @@ else:
     if not a.no_save:
         ix.save(path)
 ix.upload(0)
-q = _native.synth(a.queries, a.dim, 43, 1, docs)
+q = _native.synth(a.queries, a.dim, 43, 1, docs, collection=a.collection)
 b = _native.DeviceBatch(ix, *q, a.k)
 for _ in range(2):
     b.run(a.k, a.query_cut, a.heap_factor, bool(a.first_sorted))
