@@ -428,7 +428,11 @@ def main():
     # reference does -> algorithmic bytes of each launch
     # bytes per document element as stored: f16 2 + 2, fixed-u8 2 + 1, DotVByte 1.5 (12-byte slices of eight components) + 1
     val_bytes = 2 if args.value_type == "f16" else 1
-    doc_comp_bytes = 1.5 if args.value_type == "dotvbyte" else None
+    doc_comp_bytes = None
+    if args.value_type == "dotvbyte":   # 1.5 bytes per component in a packed slice, 2 for the documents that keep the raw form
+        raw_docs, raw_elems = index.stream_stats()
+        raw_share = raw_elems / float(max(int(d.nnz), 1))
+        doc_comp_bytes = 1.5 * (1.0 - raw_share) + 2.0 * raw_share
     algo, counted_identical, results = [], True, {}
     entry_identical = True
     agg = np.zeros(8, np.float64)

@@ -217,6 +217,11 @@ sgpu_status sgpu_index_get_knn(const sgpu_index* idx, const uint32_t** neighbour
                                uint32_t* knn_dim);
 /* Bytes resident in HBM after upload (0 before). */
 uint64_t sgpu_index_device_bytes(const sgpu_index* idx);
+/* A DotVByte index (SGPU_VAL_DOTVBYTE; reference src/pylib/dotvbyte.rs:15-22) keeps a document whose component gaps do
+ * not fit the packed stream's fields in the raw form (2 bytes per component instead of 1.5): how many documents and
+ * how many of their elements that is (0, 0 for the other value types). bench.py charges those elements their stored
+ * bytes in the algorithmic-byte count. */
+sgpu_status sgpu_index_stream_stats(const sgpu_index* idx, uint64_t* raw_docs, uint64_t* raw_elements);
 void sgpu_index_destroy(sgpu_index* idx);
 
 /* ---- search ------------------------------------------------------------ */

@@ -192,6 +192,13 @@ class NativeIndex:
     def device_bytes(self):
         return int(lib().sgpu_index_device_bytes(self.h))
 
+    def stream_stats(self):
+        """(documents, elements) a DotVByte index keeps in the raw record form; (0, 0) for the other value types."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        lib().sgpu_index_stream_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        check(lib().sgpu_index_stream_stats(self.h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def close(self):
         if self.h:
             lib().sgpu_index_destroy(self.h)

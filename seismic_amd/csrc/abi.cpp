@@ -206,6 +206,23 @@ sgpu_status sgpu_index_build_knn(sgpu_index* idx, uint32_t nknn) {
 
 uint64_t sgpu_index_device_bytes(const sgpu_index* idx) { return idx ? device_index_bytes(idx->dev) : 0; }
 
+sgpu_status sgpu_index_stream_stats(const sgpu_index* idx, uint64_t* raw_docs, uint64_t* raw_elements) {
+  if (!idx || !raw_docs || !raw_elements) return fail(SGPU_EINVAL, "null argument");
+  *raw_docs = *raw_elements = 0;
+  try {
+    std::vector<uint8_t> raw;
+    pack_dvb_raw_flags(idx->host, false, &raw);   // (empty unless the index is a DotVByte one)
+    for (uint64_t d = 0; d < raw.size(); ++d)
+      if (raw[d]) {
+        *raw_docs += 1;
+        *raw_elements += idx->host.fwd_offsets[d + 1] - idx->host.fwd_offsets[d];
+      }
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of host memory");
+  }
+  return SGPU_OK;
+}
+
 void sgpu_index_destroy(sgpu_index* idx) {
   if (!idx) return;
   drop_replicas(idx);

@@ -129,7 +129,7 @@ sgpu_status validate_desc(const sgpu_index_desc& d) {
   for (uint64_t doc = 0; doc < d.n_docs; ++doc) {
     const uint64_t s = d.fwd_offsets[doc], e = d.fwd_offsets[doc + 1];
     if (e - s > 65535) return fail(SGPU_EINVAL, "document %llu has more than 65535 components (16-bit length, reference src/posting_list.rs:45-48)", (unsigned long long)doc);
-    if (d.value_type == SGPU_VAL_DOTVBYTE && e - s > 32767) return fail(SGPU_EINVAL, "document %llu has more than 32767 components (DotVByte forward index)", (unsigned long long)doc);
+    if (d.value_type == SGPU_VAL_DOTVBYTE && e - s > 32767) return fail(SGPU_ELIMIT, "document %llu has more than 32767 components (DotVByte forward index)", (unsigned long long)doc);
     for (uint64_t i = s; i < e; ++i) {
       const uint32_t c = compv(d.fwd_comps, i);
       if (c >= d.dim) return fail(SGPU_EINVAL, "document component >= dim");

@@ -51,7 +51,6 @@ def test_two_ranks_strong_scaling_is_the_single_gpu_answer(tmp_path):
     # one batch at a time (a barrier around every step, one call per rank)
     assert "pipelined" in out["value_is"]
     assert out["value_one_batch_at_a_time"] > 0 and out["one_batch_at_a_time"]["ms_per_step"] > 0
-    assert out["value_one_batch_at_a_time"] <= out["value"] * 1.5   # (never far above the pipelined figure)
     assert int(out["host_threads_per_rank_for_host_phases"]) >= 1
 
 
