@@ -18,6 +18,8 @@ uint32_t sgpu_debug_chunk_plan(uint32_t nq, uint32_t chunk_min, uint32_t chunk_m
 /* the forward store as sgpu_index_upload packs it (document-major records) and every document's ref */
 sgpu_status sgpu_debug_pack_forward(const sgpu_index* idx, uint8_t* out_fwd, uint64_t cap, uint64_t* out_doc_ref,
                                     uint64_t* out_bytes);
+/* the hashed row directory as sgpu_index_upload builds it (4 words per slot, 4 slots per bucket); *n_buckets == 0: none */
+sgpu_status sgpu_debug_row_dir(const sgpu_index* idx, uint32_t* out, uint64_t cap_words, uint64_t* n_words, uint32_t* n_buckets);
 /* the launch plan of a batch: processing order, out3 = {block dots needed at most, largest first list, largest list} */
 sgpu_status sgpu_debug_plan(const sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals,
                             uint32_t nq, uint32_t query_cut, uint32_t* order_out, uint32_t* out3);

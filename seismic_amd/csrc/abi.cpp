@@ -592,6 +592,27 @@ sgpu_status sgpu_debug_pack_forward(const sgpu_index* idx, uint8_t* out_fwd, uin
   return SGPU_OK;
 }
 
+// (the hashed row directory as sgpu_index_upload builds it: 4 words per slot, 4 slots per bucket; out == null: *n_words
+// and *n_buckets only. *n_buckets == 0: this index gets none)
+sgpu_status sgpu_debug_row_dir(const sgpu_index* idx, uint32_t* out, uint64_t cap_words, uint64_t* n_words, uint32_t* n_buckets) {
+  SGPU_HOOK_OR(SGPU_EINVAL);
+  if (!idx || !n_words || !n_buckets) return fail(SGPU_EINVAL, "null argument");
+  try {
+    std::vector<uint16_t> mid;
+    std::vector<uint32_t> dir;
+    pack_row_mid(idx->host, &mid);
+    *n_buckets = 0;
+    if (!pack_row_dir(idx->host, mid, &dir, n_buckets)) *n_buckets = 0;
+    *n_words = dir.size();
+    if (!out) return SGPU_OK;
+    if (cap_words < dir.size()) return fail(SGPU_EINVAL, "buffer too small");
+    std::memcpy(out, dir.data(), dir.size() * 4);
+  } catch (const std::bad_alloc&) {
+    return fail(SGPU_ENOMEM, "out of host memory");
+  }
+  return SGPU_OK;
+}
+
 // (not part of the boundary: the launch plan of a batch - processing order (longest expected first), out3 = {block dots a
 // query needs at most, largest list walked first, largest list walked}; needs no device)
 sgpu_status sgpu_debug_plan(const sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals, uint32_t nq,

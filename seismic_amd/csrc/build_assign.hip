@@ -253,7 +253,10 @@ struct DevBuf {
 // device_assign_clusters then reports it.
 uint32_t device_assign_max_centroids(int device) {
   int lds = 0;
-  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || lds <= 0) return 0;
+  if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || lds <= 0) {
+    (void)hipGetLastError();   // (the runtime's sticky error must not surface at a later, unrelated hipGetLastError)
+    return 0;
+  }
   const size_t fixed = kAssignMaxCentroids / 32 * 4 + 256;   // s_avoid, s_list, alignment
   if ((size_t)lds <= fixed) return 0;
   const size_t fit = ((size_t)lds - fixed) / ((size_t)(kAssignThreads / 64) * 4);
@@ -337,6 +340,7 @@ sgpu_status device_assign_clusters(int device, uint32_t comp_width, uint64_t n_d
   v.touched_cap = touched_cap;
   v.inv_cap = std::max<uint64_t>(inv_cap, 1);
   v.queue = (uint32_t*)d_queue.p;
+  (void)hipGetLastError();   // (this launch is judged alone: an earlier failed call of the thread leaves its error behind)
   hipLaunchKernelGGL(assign_clusters_kernel, dim3(grid), dim3(kAssignThreads), lds, 0, v);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipDeviceSynchronize());

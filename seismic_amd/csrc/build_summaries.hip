@@ -323,6 +323,7 @@ sgpu_status device_block_summaries(int device, uint32_t comp_width, uint64_t n_d
       HIP_TRY(hipMemset(d_cur.p, 0, 16));
       HIP_TRY(hipMemset(d_queue.p, 0, 16));
       const uint32_t grid = (uint32_t)std::min<size_t>(last - first, (size_t)prop.multiProcessorCount * (size_t)per_cu);
+      (void)hipGetLastError();   // (this launch is judged alone: an earlier failed call of the thread leaves its error behind)
       hipLaunchKernelGGL(block_summaries_kernel, dim3(grid), dim3(kSumThreads), kLds, 0, v);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipDeviceSynchronize());

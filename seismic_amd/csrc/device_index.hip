@@ -372,6 +372,7 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     pref.shrink_to_fit();
     if ((st = dev_copy(d, h.post_doc.data(), h.post_doc.size(), &d->view.post_doc)) != SGPU_OK) return bail(st);
     if (d->fwd_block_major && h.n_postings()) {
+      (void)hipGetLastError();   // (judge this launch alone: an earlier failed call of the thread leaves its error behind)
       hipLaunchKernelGGL(replicate_records_kernel, dim3(d->n_cu * 8), dim3(256), 0, d->main.stream,
                          (uint8_t*)d->view.fwd, d->view.doc_ref, d->view.post_doc, d->view.post_ref,
                          (uint64_t)h.n_postings(), (uint32_t)(cw + vb), (uint32_t)(!dvb_raw.empty()), (uint32_t)vb);
@@ -404,6 +405,18 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       std::vector<uint16_t> mid;
       pack_row_mid(h, &mid);
       if ((st = dev_copy(d, mid.data(), mid.size(), &d->view.row_mid)) != SGPU_OK) return bail(st);
+      // hashed row directory (u16 components): a query component's summary row in one trip instead of a binary search
+      // (SGPU_ROW_DIR=0, a test hook, keeps the search)
+      d->view.row_dir = nullptr;
+      d->view.row_dir_buckets = 0;
+      std::vector<uint32_t> dir;
+      uint32_t n_buckets = 0;
+      const char* rd = hook_raw("SGPU_ROW_DIR");
+      if (!(rd && rd[0] == '0') && pack_row_dir(h, mid, &dir, &n_buckets)) {
+        static_assert(sizeof(d->view.row_dir) == sizeof(const uint32_t*), "pointer field");
+        if ((st = dev_copy(d, dir.data(), dir.size(), (const uint32_t**)&d->view.row_dir)) != SGPU_OK) return bail(st);
+        d->view.row_dir_buckets = n_buckets;
+      }
     }
     {
       // dequantised summary values: code*quant + min with the reference's two roundings
@@ -423,7 +436,9 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
     d->view.dim = (uint32_t)h.dim;
     d->view.n_docs = (uint32_t)h.n_docs;
     d->view.n_bitmap_words = (uint32_t)((h.n_docs + 31) / 32);
+#if defined(SGPU_LAZY_DOCS) && SGPU_LAZY_DOCS
     d->view.n_postings_lt_2g = h.n_postings() < (1ull << 31) ? 1u : 0u;
+#endif
     // ---- block-count statistics for LDS sizing
     d->list_nb.resize(h.dim);
     d->list_np.resize(h.dim);

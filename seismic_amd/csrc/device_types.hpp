@@ -6,6 +6,12 @@
 
 namespace sgpu {
 
+#if defined(__HIPCC__)
+#define SGPU_HD_EARLY __host__ __device__
+#else
+#define SGPU_HD_EARLY
+#endif
+
 // The index as it lies in HBM (SoA; see DESIGN.md "Data layout in HBM").
 struct DevView {
   const uint8_t* fwd;                 // document records, 16-byte aligned:
@@ -30,8 +36,22 @@ struct DevView {
   uint64_t knn_total;
   uint32_t knn_dim;
   uint32_t dim, n_docs, n_bitmap_words;
+#if defined(SGPU_LAZY_DOCS) && SGPU_LAZY_DOCS
   uint32_t n_postings_lt_2g;          // posting indices fit 31 bits (lazy document ids keep one in it_doc next to the visited bit)
+#endif
+  // Hashed row directory (r05; u16 components): (posting list, component) -> the list's summary row of that component,
+  // so that stage 1 finds a query component's row in ONE trip to HBM instead of the ~12 dependent probes of a binary
+  // search over row_comp. Buckets of four 16-byte entries {key = list << 16 | component, first entry (low 32 bits),
+  // first entry (high 16) | entries << 16, split point}; a key lives in the first bucket from row_dir_bucket(key) on
+  // that had a free slot (empty key 0xffffffff); the table is at most 60 % full (8.8M-document index: 141 M rows,
+  // 3.8 GB). null = no directory (u32 components, dim 65536): binary search.
+  const uint4* row_dir;
+  uint32_t row_dir_buckets;
 };
+enum : uint32_t { kRowDirEmpty = 0xffffffffu };
+SGPU_HD_EARLY inline uint32_t row_dir_bucket(uint32_t key, uint32_t n_buckets) {   // hash, then multiply-high onto [0, n_buckets)
+  return (uint32_t)(((uint64_t)(key * 2654435761u) * n_buckets) >> 32);
+}
 
 struct BatchView {
   const uint32_t* q_off;   // nq + 1

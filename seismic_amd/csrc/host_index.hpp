@@ -79,6 +79,7 @@ void pack_post_refs(const HostIndex& h, const std::vector<uint8_t>& raw, const s
 void pack_doc_refs(const HostIndex& h, const std::vector<uint8_t>& raw, const std::vector<uint64_t>& rec_off16, std::vector<uint64_t>* dref);
 void pack_narrow(const std::vector<uint64_t>& v, std::vector<uint32_t>* out);
 void pack_row_mid(const HostIndex& h, std::vector<uint16_t>* mid);
+bool pack_row_dir(const HostIndex& h, const std::vector<uint16_t>& mid, std::vector<uint32_t>* out, uint32_t* n_buckets);
 void pack_sum_deq(const HostIndex& h, std::vector<float>* deq);
 
 // builder.cpp

@@ -9,6 +9,10 @@
 
 namespace sgpu {
 
+static inline uint32_t row_dir_bucket_host(uint32_t key, uint32_t n_buckets) {   // == device_types.hpp: row_dir_bucket
+  return (uint32_t)(((uint64_t)(uint32_t)(key * 2654435761u) * n_buckets) >> 32);
+}
+
 // ---- compressed component stream (SGPU_VAL_DOTVBYTE: search_kernel.inc VT_DVB; and, since r05, the sliced layout of an
 // f16 index over u16 components: VT_F16S) ---------------------------------------------------------------------------
 // A document is stored as 12-byte slices of eight elements - the slice's first component in 16 bits, the gaps of
@@ -187,6 +191,41 @@ void pack_row_mid(const HostIndex& h, std::vector<uint16_t>* out) {
       mid[r] = (uint16_t)(std::lower_bound(b, e, half) - b);
     }
   }
+}
+
+// Hashed row directory (DevView::row_dir): for every summary row its {key, first entry, entries, split point} in the
+// first bucket from row_dir_bucket(key) on with a free slot; as many 4-slot buckets as leave the table at most 60 % full.
+// Built on all host threads (a slot is claimed with a compare-and-swap on its key word). Returns false when the index
+// cannot have one (u32 components, dim 65536, no rows).
+bool pack_row_dir(const HostIndex& h, const std::vector<uint16_t>& mid, std::vector<uint32_t>* out, uint32_t* n_buckets_out) {
+  out->clear();
+  const uint64_t n_rows = h.n_rows();
+  if (h.comp_width != 2 || h.dim > 65535 || n_rows == 0) return false;
+  const uint64_t n_buckets = std::max<uint64_t>(1, (n_rows * 10 / 6 + 3) / 4);   // 4-slot buckets, at most 60 % full
+  if (n_buckets >= (1ull << 31)) return false;
+  out->assign(n_buckets * 16, 0xffffffffu);   // four words per slot, every key empty
+  uint32_t* tab = out->data();
+  const uint16_t* rc = (const uint16_t*)h.row_comp.data();
+#pragma omp parallel for schedule(dynamic, 64) num_threads(sgpu::host_threads())
+  for (int64_t c = 0; c < (int64_t)h.dim; ++c)
+    for (uint64_t r = h.list_row_start[(size_t)c]; r < h.list_row_start[(size_t)c + 1]; ++r) {
+      const uint32_t key = ((uint32_t)c << 16) | rc[r];
+      const uint64_t start = h.row_ptr[r], len = h.row_ptr[r + 1] - start;
+      uint64_t b = row_dir_bucket_host(key, (uint32_t)n_buckets);
+      for (bool placed = false; !placed; b = b + 1 == n_buckets ? 0 : b + 1)
+        for (uint32_t s = 0; s < 4 && !placed; ++s) {
+          uint32_t* e = tab + (b * 4 + s) * 4;
+          uint32_t expect = 0xffffffffu;
+          if (__atomic_compare_exchange_n(&e[0], &expect, key, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+            e[1] = (uint32_t)start;
+            e[2] = (uint32_t)(start >> 32) | ((uint32_t)len << 16);
+            e[3] = mid[r];
+            placed = true;
+          }
+        }
+    }
+  *n_buckets_out = (uint32_t)n_buckets;
+  return true;
 }
 
 // Dequantised summary values: code * quant + min with the reference's two roundings

