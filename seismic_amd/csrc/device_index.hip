@@ -389,14 +389,6 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       if ((st = dev_copy(d, v.data(), v.size(), &d->view.list_block_start)) != SGPU_OK) return bail(st);
       v = narrow(h.block_post_start);
       if ((st = dev_copy(d, v.data(), v.size(), &d->view.block_post_start)) != SGPU_OK) return bail(st);
-      v = narrow(h.list_row_start);
-      if ((st = dev_copy(d, v.data(), v.size(), &d->view.list_row_start)) != SGPU_OK) return bail(st);
-      if ((st = dev_copy(d, h.row_ptr.data(), h.row_ptr.size(), &d->view.row_ptr)) != SGPU_OK) return bail(st);
-    }
-    {
-      static_assert(sizeof(d->view.row_comp) == sizeof(const uint8_t*), "pointer field");
-      if ((st = dev_copy(d, h.row_comp.data(), h.row_comp.size(), (const uint8_t**)&d->view.row_comp)) != SGPU_OK)
-        return bail(st);
     }
     if ((st = dev_copy(d, h.sum_bid.data(), h.sum_bid.size(), &d->view.sum_bid)) != SGPU_OK) return bail(st);
     {
@@ -404,18 +396,32 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
       // id, validate_desc): stage 1 gives each half of a list to its own wavefront
       std::vector<uint16_t> mid;
       pack_row_mid(h, &mid);
-      if ((st = dev_copy(d, mid.data(), mid.size(), &d->view.row_mid)) != SGPU_OK) return bail(st);
-      // hashed row directory (u16 components): a query component's summary row in one trip instead of a binary search
-      // (SGPU_ROW_DIR=0, a test hook, keeps the search)
+      d->view.list_row_start = nullptr;
+      d->view.row_ptr = nullptr;
+      d->view.row_comp = nullptr;
+      d->view.row_mid = nullptr;
       d->view.row_dir = nullptr;
       d->view.row_dir_buckets = 0;
-      std::vector<uint32_t> dir;
-      uint32_t n_buckets = 0;
-      const char* rd = hook_raw("SGPU_ROW_DIR");
-      if (!(rd && rd[0] == '0') && pack_row_dir(h, mid, &dir, &n_buckets)) {
+      if (cw == 2) {
+        // u16 components: the hashed row directory IS the row index on the device - a query component's summary row
+        // {first entry, entries, split point} in one trip (search_kernel.inc: build_row_table); the CSR arrays the
+        // binary search of the u32 kernels walks (row_comp, row_ptr, row_mid, list_row_start: 1.7 GB for the 8.8M-document
+        // index) are not uploaded at all.
+        std::vector<uint32_t> dir;
+        uint32_t n_buckets = 0;
+        if (!pack_row_dir(h, mid, &dir, &n_buckets))
+          return bail(fail(SGPU_ELIMIT, "the summary rows of this index do not fit the row directory (u16 components need dim <= 65535)"));
         static_assert(sizeof(d->view.row_dir) == sizeof(const uint32_t*), "pointer field");
         if ((st = dev_copy(d, dir.data(), dir.size(), (const uint32_t**)&d->view.row_dir)) != SGPU_OK) return bail(st);
         d->view.row_dir_buckets = n_buckets;
+      } else {
+        auto v = narrow(h.list_row_start);
+        if ((st = dev_copy(d, v.data(), v.size(), &d->view.list_row_start)) != SGPU_OK) return bail(st);
+        if ((st = dev_copy(d, h.row_ptr.data(), h.row_ptr.size(), &d->view.row_ptr)) != SGPU_OK) return bail(st);
+        static_assert(sizeof(d->view.row_comp) == sizeof(const uint8_t*), "pointer field");
+        if ((st = dev_copy(d, h.row_comp.data(), h.row_comp.size(), (const uint8_t**)&d->view.row_comp)) != SGPU_OK)
+          return bail(st);
+        if ((st = dev_copy(d, mid.data(), mid.size(), &d->view.row_mid)) != SGPU_OK) return bail(st);
       }
     }
     {
@@ -1062,8 +1068,8 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   // (measured r03 on the 8.8M-document shape, u16 components: 6.46 ms per launch against the dense byte
   // table's 5.81 - a random 8-byte read costs two bank passes where the byte read costs one and the dense
   // layout's second read is mostly a broadcast of one address; fixed-u8 6.36 against 5.56. The hashed
-  // entries therefore serve u32 components, where they replace a byte read PLUS an 8-byte read; for u16
-  // they are used when the dense table is not available or on request, SGPU_FORCE_HASH=1.)
+  // entries therefore serve u32 components, where they replace a byte read PLUS an 8-byte read; the u16
+  // hashed families were dropped in r05 - u16 components use the dense table or the packed words.)
   bool hashed = searching && hash_family && pl && pl->hash_ok && !hook_u32("SGPU_NO_LPT", 0) && !hook_u32("SGPU_NO_HASH", 0) &&
                 !hook_u32("SGPU_FORCE_SPLIT", 0) && !hook_u32("SGPU_FORCE_DENSE", 0) &&
                 (d->comp_width == 4 || !dense || hook_u32("SGPU_FORCE_HASH", 0));

@@ -44,7 +44,8 @@ struct DevView {
   // search over row_comp. Buckets of four 16-byte entries {key = list << 16 | component, first entry (low 32 bits),
   // first entry (high 16) | entries << 16, split point}; a key lives in the first bucket from row_dir_bucket(key) on
   // that had a free slot (empty key 0xffffffff); the table is at most 60 % full (8.8M-document index: 141 M rows,
-  // 3.8 GB). null = no directory (u32 components, dim 65536): binary search.
+  // 3.8 GB). Every u16 index has one (its kernels carry no search and row_comp / list_row_start / row_ptr / row_mid
+  // stay null); u32 indexes have none: binary search over those arrays.
   const uint4* row_dir;
   uint32_t row_dir_buckets;
 };

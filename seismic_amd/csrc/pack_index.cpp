@@ -196,11 +196,11 @@ void pack_row_mid(const HostIndex& h, std::vector<uint16_t>* out) {
 // Hashed row directory (DevView::row_dir): for every summary row its {key, first entry, entries, split point} in the
 // first bucket from row_dir_bucket(key) on with a free slot; as many 4-slot buckets as leave the table at most 60 % full.
 // Built on all host threads (a slot is claimed with a compare-and-swap on its key word). Returns false when the index
-// cannot have one (u32 components, dim 65536, no rows).
+// cannot have one (u32 components, dim 65536).
 bool pack_row_dir(const HostIndex& h, const std::vector<uint16_t>& mid, std::vector<uint32_t>* out, uint32_t* n_buckets_out) {
   out->clear();
   const uint64_t n_rows = h.n_rows();
-  if (h.comp_width != 2 || h.dim > 65535 || n_rows == 0) return false;
+  if (h.comp_width != 2 || h.dim > 65535) return false;   // (an index without rows gets one empty bucket)
   const uint64_t n_buckets = std::max<uint64_t>(1, (n_rows * 10 / 6 + 3) / 4);   // 4-slot buckets, at most 60 % full
   if (n_buckets >= (1ull << 31)) return false;
   out->assign(n_buckets * 16, 0xffffffffu);   // four words per slot, every key empty

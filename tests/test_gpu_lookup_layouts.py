@@ -1,6 +1,7 @@
 """Every query lookup layout returns the oracle's results: the hashed {component id, weight} entries (one LDS
-read per document component; the default for u32 components) forced onto the fuzz seeds - u16 and u32
-components, f16 and fixed-u8 values, 512- and 1024-thread workgroups, cooperative and plain launches."""
+read per document component; the u32 layout) asked for on the fuzz seeds - seeds with u32 components and f16 values run
+them, the others (u16 components: the hashed families were dropped in r05; fixed-u8 over u32) their own layout -
+512- and 1024-thread workgroups, cooperative and plain launches."""
 import pytest
 
 from test_gpu_fuzz import test_differential as _differential

@@ -1,13 +1,9 @@
-export SGPU_INDEX_CACHE=/tmp SGPU_TEST_HOOKS=1
-O=gpurun_out/r05q; mkdir -p $O
-T1=$PWD/seismic_amd/libseismic_hip_t1.so
-SGPU_LIB=$T1 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_coop.py tests/test_gpu_api_and_scale.py -x -q -m gpu > $O/pytest_subset.txt 2>&1; tail -n 3 $O/pytest_subset.txt
-B="python bench.py --no-cpu --no-e2e --no-entry --no-latency --target-recall= --index-cache /tmp"
-for i in 1 2 3; do
-SGPU_LIB=$T1 $B > $O/bench_t1_$i.json 2> $O/bench_t1_$i.err; python -c "import json;d=json.load(open('$O/bench_t1_$i.json'));print('t1     ', d['roofline']['kernel_ms'], d['roofline']['frac'])"
-$B > $O/bench_base_$i.json 2> $O/bench_base_$i.err; python -c "import json;d=json.load(open('$O/bench_base_$i.json'));print('base   ', d['roofline']['kernel_ms'], d['roofline']['frac'])"
-done
-SGPU_LIB=$T1 $B --collection clustered > $O/bench_clu_t1.json 2> $O/bench_clu_t1.err; python -c "import json;d=json.load(open('$O/bench_clu_t1.json'));print('clustered t1  ', d['roofline']['kernel_ms'], d['roofline']['frac'])"
-$B --collection clustered > $O/bench_clu_base.json 2> $O/bench_clu_base.err; python -c "import json;d=json.load(open('$O/bench_clu_base.json'));print('clustered base', d['roofline']['kernel_ms'], d['roofline']['frac'])"
-SGPU_LIB=$T1 $B --value-type fixedu8 > $O/bench_u8_t1.json 2> $O/bench_u8_t1.err; python -c "import json;d=json.load(open('$O/bench_u8_t1.json'));print('u8 t1  ', d['roofline']['kernel_ms'], d['roofline']['frac'])"
-$B --value-type fixedu8 > $O/bench_u8_base.json 2> $O/bench_u8_base.err; python -c "import json;d=json.load(open('$O/bench_u8_base.json'));print('u8 base', d['roofline']['kernel_ms'], d['roofline']['frac'])"
+export SGPU_INDEX_CACHE=/tmp
+O=gpurun_out/r05r; mkdir -p $O
+python -m pytest tests -q -m gpu > $O/gpu_suite.log 2>&1; tail -n 4 $O/gpu_suite.log
+rm -rf gpurun_out/r05_prof gpurun_out/r05_traffic_* gpurun_out/r05_single
+tools/profile_round.sh r05 > gpurun_out/r05_profile_round.log 2>&1; tail -n 3 gpurun_out/r05_profile_round.log
+C5="--docs 5000000 --dim 200000 --comp-width 4 --k 100 --query-cut 10 --heap-factor 0.9 --n-postings 2000 --centroid-fraction 0.1 --summary-energy 0.4 --max-fraction 4 --min-cluster-size 10 --queries 2000 --steps 5 --warmup 1 --target-recall="
+python bench.py $C5 > $O/bench_c5.json 2> $O/bench_c5.err; tail -c 200 $O/bench_c5.err
+python -c "import json;d=json.load(open('$O/bench_c5.json'));print('c5', d['value'], d['roofline']['kernel_ms'], d['roofline']['frac'], d.get('recall_at_k'), d.get('mean_latency_us_single_query'))"
+tools/profile_traffic.sh gpurun_out/r05_traffic_c5 $C5 > $O/traffic_c5.txt 2>&1; tail -n 10 $O/traffic_c5.txt
