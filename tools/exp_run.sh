@@ -1,9 +1,4 @@
 export SGPU_INDEX_CACHE=/tmp
-O=gpurun_out/r05r; mkdir -p $O
-python -m pytest tests -q -m gpu > $O/gpu_suite.log 2>&1; tail -n 4 $O/gpu_suite.log
-rm -rf gpurun_out/r05_prof gpurun_out/r05_traffic_* gpurun_out/r05_single
-tools/profile_round.sh r05 > gpurun_out/r05_profile_round.log 2>&1; tail -n 3 gpurun_out/r05_profile_round.log
-C5="--docs 5000000 --dim 200000 --comp-width 4 --k 100 --query-cut 10 --heap-factor 0.9 --n-postings 2000 --centroid-fraction 0.1 --summary-energy 0.4 --max-fraction 4 --min-cluster-size 10 --queries 2000 --steps 5 --warmup 1 --target-recall="
-python bench.py $C5 > $O/bench_c5.json 2> $O/bench_c5.err; tail -c 200 $O/bench_c5.err
-python -c "import json;d=json.load(open('$O/bench_c5.json'));print('c5', d['value'], d['roofline']['kernel_ms'], d['roofline']['frac'], d.get('recall_at_k'), d.get('mean_latency_us_single_query'))"
-tools/profile_traffic.sh gpurun_out/r05_traffic_c5 $C5 > $O/traffic_c5.txt 2>&1; tail -n 10 $O/traffic_c5.txt
+tools/profile_traffic.sh gpurun_out/r05_traffic_r90 --n-postings 4000 --max-fraction 3 --query-cut 6 > gpurun_out/r05_tr90.txt 2>&1; tail -n 9 gpurun_out/r05_tr90.txt
+tools/profile_traffic.sh gpurun_out/r05_traffic_r95 --n-postings 3000 --max-fraction 4 --query-cut 11 > gpurun_out/r05_tr95.txt 2>&1; tail -n 9 gpurun_out/r05_tr95.txt
+tools/profile_traffic.sh gpurun_out/r05_traffic_r99 --n-postings 6000 --max-fraction 4 --query-cut 13 > gpurun_out/r05_tr99.txt 2>&1; tail -n 9 gpurun_out/r05_tr99.txt

@@ -9,9 +9,9 @@ TAG="$1"
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$REPO"
 tools/profile_bench.sh gpurun_out/${TAG}_prof
-tools/profile_traffic.sh gpurun_out/${TAG}_traffic_r90 --n-postings 4000 --max-fraction 3 --query-cut 5
-tools/profile_traffic.sh gpurun_out/${TAG}_traffic_r95 --n-postings 3000 --max-fraction 4 --query-cut 10
-tools/profile_traffic.sh gpurun_out/${TAG}_traffic_r99 --n-postings 6000 --max-fraction 4 --query-cut 12
+tools/profile_traffic.sh gpurun_out/${TAG}_traffic_r90 --n-postings 4000 --max-fraction 3 --query-cut 6
+tools/profile_traffic.sh gpurun_out/${TAG}_traffic_r95 --n-postings 3000 --max-fraction 4 --query-cut 11
+tools/profile_traffic.sh gpurun_out/${TAG}_traffic_r99 --n-postings 6000 --max-fraction 4 --query-cut 13
 tools/profile_traffic.sh gpurun_out/${TAG}_traffic_fixedu8 --value-type fixedu8
 tools/profile_traffic.sh gpurun_out/${TAG}_traffic_dotvbyte --value-type dotvbyte
 tools/profile_traffic.sh gpurun_out/${TAG}_traffic_first_sorted --first-sorted 1
