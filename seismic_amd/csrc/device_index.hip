@@ -244,9 +244,10 @@ __global__ __launch_bounds__(256) void replicate_records_kernel(uint8_t* fwd, co
   for (uint64_t p = g; p < n_postings; p += n_groups) {
     const uint64_t dst = post_ref[p], src = doc_ref[post_doc[p]];
     uint32_t n16;   // 16-byte units of the record
-    if (dvb && !(dst & 0x8000u)) {   // sliced: [ns x 12 B gaps][pad to 8 / 16][ns x 8 values of 1 / 2 bytes]
+    if (dvb && !(dst & 0x8000u)) {   // sliced record (pack_index.cpp: record_bytes)
       const uint32_t ns = (((uint32_t)dst & 0x7fffu) + 7u) >> 3, vb8 = 8u * val_bytes;
-      n16 = ((((ns * 12u + vb8 - 1u) & ~(vb8 - 1u)) + ns * vb8) + 15u) >> 4;
+      n16 = val_bytes == 1 ? (ns * 20u + 15u) >> 4                                          // DotVByte: [ns x 16 B][ns x 4 B]
+                           : ((((ns * 12u + vb8 - 1u) & ~(vb8 - 1u)) + ns * vb8) + 15u) >> 4;   // sliced f16
     } else {
       const uint32_t len = (uint32_t)dst & (dvb ? 0x7fffu : 0xffffu);
       n16 = (((len + 7u) & ~7u) * bytes_per_elem + 15u) >> 4;

@@ -48,8 +48,9 @@ bool pack_f16_slices_possible(const HostIndex& h) {
 static inline uint64_t record_bytes(const HostIndex& h, const std::vector<uint8_t>& raw, uint64_t doc, uint64_t len) {
   const uint64_t npad = (len + 7) & ~7ull;
   if (!raw.empty() && !raw[doc]) {
-    const uint64_t ns = npad / 8, vb8 = 8ull * h.val_bytes();   // [ns x 12 B gaps][pad to the values' 8 / 16 B][ns x 8 values]
-    return ((ns * 12 + vb8 - 1) & ~(vb8 - 1)) + ns * vb8;
+    const uint64_t ns = npad / 8, vb8 = 8ull * h.val_bytes();
+    if (h.val_bytes() == 1) return ns * 20;   // DotVByte (r05): [ns x 16 B: w0 w1 w2 | codes 0-3][ns x 4 B: codes 4-7]
+    return ((ns * 12 + vb8 - 1) & ~(vb8 - 1)) + ns * vb8;   // sliced f16: [ns x 12 B gaps][pad to 16 B][ns x 8 binary16 values]
   }
   return npad * (h.comp_width + h.val_bytes());
 }
@@ -93,7 +94,31 @@ void pack_records(const HostIndex& h, const std::vector<uint8_t>& raw, const std
       const uint64_t ns = npad / 8;
       uint32_t* gw = (uint32_t*)rec;
       const uint64_t vb8 = 8ull * vb;
-      uint8_t* codes = rec + ((ns * 12 + vb8 - 1) & ~(vb8 - 1));   // (the values: u8 codes, or binary16 for the sliced f16 layout)
+      uint8_t* codes = rec + ((ns * 12 + vb8 - 1) & ~(vb8 - 1));   // (sliced f16: the binary16 values behind the 12-byte slices)
+      if (vb == 1) {
+        // DotVByte (r05): a slice's three gap words and its first four codes share ONE aligned 16-byte unit, the other
+        // four codes follow in a dword array: [ns x 16 B][ns x 4 B] (until r04: [ns x 12 B][pad][ns x 8 B])
+        const uint8_t* cd = h.fwd_codes.data() + s0;
+        uint32_t* hi = (uint32_t*)(rec + ns * 16);
+        for (uint64_t sl = 0; sl < ns; ++sl) {
+          uint32_t g[8], cw[2] = {0, 0};
+          g[0] = comps[sl * 8];
+          for (uint64_t i = 1; i < 8; ++i) {
+            const uint64_t e = sl * 8 + i;
+            g[i] = e < len ? (uint32_t)comps[e] - (uint32_t)comps[e - 1] : 0u;
+          }
+          for (uint64_t i = 0; i < 8; ++i) {
+            const uint64_t e = sl * 8 + i;
+            if (e < len) cw[i >> 2] |= (uint32_t)cd[e] << (8 * (i & 3));
+          }
+          gw[4 * sl + 0] = g[0] | (g[1] << 16) | (g[2] << 28);
+          gw[4 * sl + 1] = (g[2] >> 4) | (g[3] << 8) | (g[4] << 20) | (g[5] << 31);
+          gw[4 * sl + 2] = (g[5] >> 1) | (g[6] << 10) | (g[7] << 21);
+          gw[4 * sl + 3] = cw[0];
+          hi[sl] = cw[1];
+        }
+        continue;
+      }
       for (uint64_t sl = 0; sl < ns; ++sl) {
         uint32_t g[8];
         g[0] = comps[sl * 8];
@@ -105,8 +130,7 @@ void pack_records(const HostIndex& h, const std::vector<uint8_t>& raw, const std
         gw[3 * sl + 1] = (g[2] >> 4) | (g[3] << 8) | (g[4] << 20) | (g[5] << 31);
         gw[3 * sl + 2] = (g[5] >> 1) | (g[6] << 10) | (g[7] << 21);
       }
-      if (vb == 2) std::memcpy(codes, h.fwd_vals.data() + s0, len * 2);
-      else std::memcpy(codes, h.fwd_codes.data() + s0, len);
+      std::memcpy(codes, h.fwd_vals.data() + s0, len * 2);
       continue;
     }
     std::memcpy(rec, h.fwd_comps.data() + s0 * cw, len * cw);
