@@ -21,6 +21,8 @@ void device_index_free(DeviceIndex* d);
 uint64_t device_index_bytes(const DeviceIndex* d);
 Lane* lane_acquire(DeviceIndex* d);
 Lane* lane_try_acquire(DeviceIndex* d);
+bool call_enter(DeviceIndex* d);
+void call_exit(DeviceIndex* d);
 uint32_t coop_auto_max_queries(const DeviceIndex* d);
 void lane_release(DeviceIndex* d, Lane* l);
 Lane* lane_main(DeviceIndex* d);
@@ -347,11 +349,23 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
     Lane* lane;
     uint32_t q0, q1;
   };
-  static const uint32_t chunk_max = [] {   // (experiments: SGPU_CHUNK_MAX; the default of four was the fastest measured)
+  // Chunks per call: FOUR when this call is alone on the replica (its host side - validation, plan, staging: ~0.2 us per
+  // query - hides behind its own earlier chunks' kernels: 1.44 M queries/s from one request thread against 1.31 / 1.11 M
+  // with two / one chunk), TWO when other calls are - or were a moment ago - in flight on it (their kernels hide it, and every extra chunk is a launch
+  // tail: 10 000-query calls from two / three request threads 1.670 / 1.683 M queries/s with two chunks against 1.636 /
+  // 1.596 M with four - the device-resident rate is 1.685 M; r05, gpurun_out r05y). SGPU_CHUNK_MAX fixes the number.
+  static const uint32_t chunk_max_env = [] {
     const char* v = std::getenv("SGPU_CHUNK_MAX");
-    const uint32_t n = v && *v ? (uint32_t)std::strtoul(v, nullptr, 10) : 4u;
-    return n < 1 ? 1u : (n > 8 ? 8u : n);
+    const uint32_t n = v && *v ? (uint32_t)std::strtoul(v, nullptr, 10) : 0u;
+    return n > 8 ? 8u : n;
   }();
+  struct InFlight {   // (counts this call on the replica for as long as it runs)
+    DeviceIndex* d;
+    bool shared;
+    explicit InFlight(DeviceIndex* d_) : d(d_), shared(call_enter(d_)) {}
+    ~InFlight() { call_exit(d); }
+  } in_flight(d);
+  const uint32_t chunk_max = chunk_max_env ? chunk_max_env : (in_flight.shared ? 2u : 4u);
   Job jobs[8];
   // Mid-size shards (SGPU_TAIL_COOP = n, an experiment, off by default): more queries than the cooperative variant takes
   // on its own, fewer than two chunks - the last n queries go out as a second launch on another lane, small enough for

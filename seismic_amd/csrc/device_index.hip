@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -125,6 +126,8 @@ struct DeviceIndex {
   Lane pool[kPool];
   std::unordered_map<uint64_t, int> occupancy;   // kernel variant + LDS size -> workgroups per CU
   std::mutex mu;        // main lane, occupancy cache
+  std::atomic<uint32_t> calls_inflight{0};               // entry-point calls on this replica right now (call_enter / call_exit)
+  std::atomic<int64_t> concurrent_seen_us{-(int64_t)1 << 60};   // when two of them were last seen together
   std::mutex pool_mu;   // pool lane hand-out
   std::condition_variable pool_cv;
 };
@@ -188,6 +191,23 @@ Lane* lane_try_acquire(DeviceIndex* d) {
       return &l;
     }
   return nullptr;
+}
+
+// Is this replica serving several calls at a time? call_enter() = true when another entry-point call is in flight on it
+// now or was within the last 50 ms (abi.cpp then cuts a large call into fewer chunks: the other calls' kernels already
+// hide this call's host side). The short memory matters: request threads that run in lockstep enter at the same instant,
+// and the first of them would see an idle replica every time.
+static inline int64_t mono_us() {
+  return (int64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+bool call_enter(DeviceIndex* d) {
+  const uint32_t n = d->calls_inflight.fetch_add(1, std::memory_order_relaxed) + 1u;
+  const int64_t now = mono_us();
+  if (n > 1) d->concurrent_seen_us.store(now, std::memory_order_relaxed);
+  return n > 1 || now - d->concurrent_seen_us.load(std::memory_order_relaxed) < 50000;
+}
+void call_exit(DeviceIndex* d) {
+  if (d->calls_inflight.fetch_sub(1, std::memory_order_relaxed) > 1u) d->concurrent_seen_us.store(mono_us(), std::memory_order_relaxed);
 }
 
 void lane_release(DeviceIndex* d, Lane* l) {
@@ -1481,7 +1501,9 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     b->staged = true;
     b->device = d->device;
     b->owner = d;
-    b->arena_cap = std::max<size_t>(total + total / 4, 1 << 16);   // some room: a stream of similar calls settles
+    // twice the need: a lane that has served one chunk of a call cut in four also holds a chunk of a call cut in two (the
+    // number of chunks follows the load of the replica, abi.cpp) - no pinned reallocation in the middle of a stream of calls
+    b->arena_cap = std::max<size_t>(total * 5 / 2, 1 << 16);   // (2.5 x: chunks of one call differ by a few per cent in components)
     if (hipMalloc((void**)&b->arena_dev, b->arena_cap) != hipSuccess ||
         hipHostMalloc((void**)&b->arena_host, b->arena_cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {   // (fine-grained by request, not by the runtime's default: the kernel's rows and done word must be visible as they land)
       batch_free(b);
