@@ -1,9 +1,12 @@
 export SGPU_INDEX_CACHE=/tmp
-O=gpurun_out/r05z4; mkdir -p $O
-B="python bench.py --no-cpu --no-latency --no-recall --no-e2e --target-recall= --index-cache /tmp"
-for w in 3 10 3 10; do
-$B --warmup $w > $O/v_w$w.json 2> /dev/null
-python -c "import json;d=json.load(open('$O/v_w$w.json'));print('warmup $w value',round(d['value']),'resident',round(d['device_resident']['value']),'ms_per_step',d['ms_per_step'])"
-done
-SGPU_CHUNK_MAX=2 $B --warmup 3 > $O/v_cm2.json 2> /dev/null; python -c "import json;d=json.load(open('$O/v_cm2.json'));print('CHUNK_MAX=2 warmup 3 value',round(d['value']))"
-SGPU_CHUNK_MAX=4 $B --warmup 3 > $O/v_cm4.json 2> /dev/null; python -c "import json;d=json.load(open('$O/v_cm4.json'));print('CHUNK_MAX=4 warmup 3 value',round(d['value']))"
+O=gpurun_out/r05final2; mkdir -p $O
+python bench.py > $O/bench_final.json 2> $O/bench_final.err; tail -c 200 $O/bench_final.err
+python - <<PY
+import json
+d=json.load(open('$O/bench_final.json'))
+print('value',d['value'],'frac',d['roofline']['frac'],'kernel_ms',d['roofline']['kernel_ms'],'traffic',d['roofline']['traffic'],'lat',d.get('mean_latency_us_single_query'),'resident',d['device_resident']['value'])
+for p in d.get('operating_points',[]):
+    print(p['target_recall'],p['reached'],p.get('recall_heldout'),p.get('value'),p.get('device_resident_qps'),p.get('roofline_frac'),p.get('entry_point_calls'))
+print(d['cpu_baseline']['value'], d['gpu_over_cpu_allcore'], d['timing_s'])
+PY
+python -m pytest tests/test_gpu_bench_multirank.py -q -m gpu > $O/pytest.txt 2>&1; tail -n 2 $O/pytest.txt
