@@ -1,4 +1,3 @@
 export SGPU_INDEX_CACHE=/tmp
-O=gpurun_out/r05soak2; mkdir -p $O
-SGPU_TEST_HOOKS=1 timeout 900 python tools/soak.py 446 646 fuzz-only > $O/soak_plain.log 2>&1; tail -n 1 $O/soak_plain.log
-SGPU_TEST_HOOKS=1 SGPU_COOP=force timeout 600 python tools/soak.py 646 746 fuzz-only > $O/soak_coop.log 2>&1; tail -n 1 $O/soak_coop.log
+O=gpurun_out/r05proxy; mkdir -p $O
+SGPU_TEST_HOOKS=1 timeout 700 python tools/proxy_probe.py $O/proxy.npz > $O/proxy.log 2>&1; tail -n 3 $O/proxy.log
