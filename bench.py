@@ -513,6 +513,7 @@ def main():
         "device_resident": {"value": total_q_per_step * args.steps / k_elapsed, "unit": "queries/s",
                             "ms_per_step": k_elapsed * 1e3 / args.steps,
                             "note": "the same batches already in HBM, results left in HBM: one kernel launch per step (the r01/r02 `value`)"},
+        "library": _native.build_info() + (" (matches this tree)" if _native.source_fingerprint() in _native.build_info() else " (NOT the build of this tree: %s)" % _native.source_fingerprint()),
         "roofline": {
             "bound": "hbm",
             "achieved": achieved,

@@ -165,6 +165,10 @@ typedef struct sgpu_launch_stats {
 const char* sgpu_last_error(void);
 /* ABI version of this header (bumped on any layout change). */
 uint32_t sgpu_abi_version(void);
+/* What this binary was built from: "sources <16 hex digits> arch gfx950 extra [<flags>] HIP version: ...". The hex
+   digits are the first 64 bits of the SHA-256 of the library's source files in a fixed order (seismic_amd/csrc/Makefile,
+   SOURCES); seismic_amd._native.source_fingerprint() recomputes them from a source tree. Static storage. */
+const char* sgpu_build_info(void);
 /* Number of visible HIP devices; SGPU_EDEVICE (and *n = 0) when none. */
 sgpu_status sgpu_device_count(int32_t* n);
 

@@ -32,6 +32,7 @@ def lib():
                 "there is no CPU fallback for the search path" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         L.sgpu_last_error.restype = C.c_char_p
+        L.sgpu_build_info.restype = C.c_char_p
         L.sgpu_abi_version.restype = C.c_uint32
         L.sgpu_index_device_bytes.restype = C.c_uint64
         L.sgpu_index_device_bytes.argtypes = [C.c_void_p]
@@ -89,6 +90,28 @@ def check(status):
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def build_info():
+    """What the loaded library says it was built from (sgpu_build_info)."""
+    return lib().sgpu_build_info().decode("utf-8", "replace")
+
+
+def source_fingerprint(root=None):
+    """The fingerprint sgpu_build_info() carries, recomputed from a source tree (default: the one this module lives in):
+    first 64 bits of the SHA-256 of seismic_amd/csrc/{*.hip,*.cpp,*.hpp,*.inc} by name, the Makefile, include/*.h by name -
+    the order of SOURCES in seismic_amd/csrc/Makefile."""
+    import glob
+    import hashlib
+    pkg = os.path.join(root, "seismic_amd") if root else os.path.dirname(os.path.abspath(__file__))
+    csrc = os.path.join(pkg, "csrc")
+    files = sorted((p for ext in ("hip", "cpp", "hpp", "inc") for p in glob.glob(os.path.join(csrc, "*." + ext))), key=os.path.basename)
+    files += [os.path.join(csrc, "Makefile")] + sorted(glob.glob(os.path.join(os.path.dirname(pkg), "include", "*.h")), key=os.path.basename)
+    h = hashlib.sha256()
+    for p in files:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def device_count():

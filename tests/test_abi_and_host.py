@@ -29,6 +29,21 @@ def test_every_declared_symbol_is_exported():
     assert L.sgpu_abi_version() == 4
 
 
+def test_the_library_is_the_build_of_this_tree():
+    """sgpu_build_info() carries a fingerprint of the sources the binary was compiled from; it must be the fingerprint of
+    the sources next to it (the prebuilt .so travels to the GPU box with the tree: a stale one would run there unnoticed).
+    The profiling build is checked when present."""
+    want = _native.source_fingerprint()
+    info = _native.build_info()
+    assert info.startswith("sources %s arch gfx950 extra [] " % want), (info, want)
+    prof = os.path.join(os.path.dirname(_native.__file__), "libseismic_hip_prof.so")
+    if os.path.exists(prof) and os.path.abspath(prof) != os.path.abspath(_native.LIB_PATH):
+        import ctypes
+        L = ctypes.CDLL(prof)
+        L.sgpu_build_info.restype = ctypes.c_char_p
+        assert L.sgpu_build_info().decode().startswith("sources %s arch gfx950 extra [-DSGPU_PROF]" % want)
+
+
 def test_test_hooks_are_inert_without_the_switch(monkeypatch):
     """The sgpu_debug_* entry points (include/seismic_hip_testing.h) and the undocumented environment names only work
     while SGPU_TEST_HOOKS=1 is set - the suite's conftest sets it; a deployment does not."""

@@ -33,6 +33,15 @@ def _same(gpu, cpu):
         assert np.array_equal(gs[q, :n].view(np.uint32), cs[q, :n].view(np.uint32)), q
 
 
+def test_the_library_loaded_on_this_box_is_the_build_of_this_tree():
+    """(the GPU box runs a prebuilt .so: this is where a stale one would show)"""
+    info = _native.build_info()
+    print(info)
+    if os.environ.get("SGPU_LIB"):
+        pytest.skip("an experiment library was asked for: " + info)
+    assert info.startswith("sources %s arch gfx950 extra [] " % _native.source_fingerprint()), info
+
+
 def test_query_cut_zero_selects_no_list():
     """k_largest_by(0) selects nothing: the reference returns an empty result (src/inverted_index.rs:187-190)."""
     ix, dim = _index()
