@@ -156,15 +156,43 @@ def kernel_source_id():
     return h.hexdigest()[:16]
 
 
+_CODE_IDS = None
+
+
+def loaded_code_ids():
+    """Machine-code identity of the 512-thread search-kernel symbols of the library this process loaded
+    (tools/kernel_code_id.py: sha256 of a symbol's disassembled instructions); {} when the LLVM tools are missing."""
+    global _CODE_IDS
+    if _CODE_IDS is None:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import kernel_code_id
+            from seismic_amd import _native
+            _CODE_IDS = kernel_code_id.code_ids(_native.LIB_PATH, r"seismic_search_kernel<unsigned (short|int), 512, ")
+        except Exception as e:   # noqa: BLE001  (bookkeeping only: the figure is then reported as unknown)
+            print("bench: kernel code ids unavailable: %r" % (e,), file=sys.stderr)
+            _CODE_IDS = {}
+    return _CODE_IDS
+
+
 def recorded_traffic(key):
     """roofline.traffic: HBM bytes per launch from SEPARATE rocprofv3 --pmc passes of this command (counters
     cannot be collected from inside this process), recorded in profiles/pmc_traffic.json under the workload
-    AND the kernel source they were measured on; anything else (another workload, a kernel edited since) is null."""
+    AND the kernel they were measured on - the kernel source's id, or the machine code of the symbol the passes ran
+    (an edit to another instantiation of the template leaves that code as it was); anything else (another workload,
+    a kernel edited since) is null."""
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         ent = pm.get("workloads", {}).get(key)
         if ent and ent.get("kernel_source_id") == kernel_source_id():
             return float(ent["traffic_bytes"]), None
+        if ent and ent.get("symbol_code_id"):
+            have = loaded_code_ids().get(ent["symbol"].replace("seismic_search_kernel", ""))
+            if have == ent["symbol_code_id"]:
+                return float(ent["traffic_bytes"]), "recorded at kernel source %s on %s, whose machine code (id %s) is the one in this library (kernel source %s)" % (
+                    ent.get("kernel_source_id"), ent["symbol"], have, kernel_source_id())
+            return None, "recorded for %s with machine code %s (kernel source %s); this library has %s" % (
+                ent["symbol"], ent["symbol_code_id"], ent.get("kernel_source_id"), have)
         if ent:
             return None, "recorded for kernel source %s, this is %s" % (ent.get("kernel_source_id", "(unrecorded)"), kernel_source_id())
     except (OSError, ValueError, KeyError):
