@@ -16,3 +16,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_cooperative_kernel_symbols_match_the_verified_build():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_coop_asm.py"), "--check"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_recorded_traffic_is_keyed_by_the_machine_code_it_was_measured_on():
+    """profiles/pmc_traffic.json: every entry of the current round names the symbol its counter passes ran and that symbol's
+    machine-code id (tools/kernel_code_id.py); bench.recorded_traffic() reports an entry only for that code (or that kernel
+    source). The ids of the built library are well formed, and an entry whose id differs is refused with the reason."""
+    import json
+    import re
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import kernel_code_id
+    ids = kernel_code_id.code_ids(pattern=r"seismic_search_kernel<unsigned short, 512, 1, 1, false, [012], false>")
+    assert len(ids) == 3 and all(re.fullmatch(r"[0-9a-f]{16}", v) for v in ids.values()), ids
+    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"]
+    keyed = {k: e for k, e in pm.items() if e.get("symbol_code_id")}
+    assert keyed, "no entry carries a machine-code id"
+    for k, e in keyed.items():
+        got, note = bench.recorded_traffic(k)
+        have = bench.loaded_code_ids().get(e["symbol"].replace("seismic_search_kernel", ""))
+        if e.get("kernel_source_id") == bench.kernel_source_id() or have == e["symbol_code_id"]:
+            assert got == float(e["traffic_bytes"])
+        else:   # the kernel was edited since: no figure, and the line says why
+            assert got is None and e["symbol_code_id"] in note
