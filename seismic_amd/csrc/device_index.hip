@@ -127,7 +127,7 @@ struct DeviceIndex {
   std::unordered_map<uint64_t, int> occupancy;   // kernel variant + LDS size -> workgroups per CU
   std::mutex mu;        // main lane, occupancy cache
   std::atomic<uint32_t> calls_inflight{0};               // entry-point calls on this replica right now (call_enter / call_exit)
-  std::atomic<int64_t> concurrent_seen_us{-(int64_t)1 << 60};   // when two of them were last seen together
+  std::atomic<int64_t> concurrent_seen_us{-((int64_t)1 << 60)};   // when two of them were last seen together
   std::mutex pool_mu;   // pool lane hand-out
   std::condition_variable pool_cv;
 };
