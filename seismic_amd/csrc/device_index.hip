@@ -136,6 +136,7 @@ static sgpu_status lane_init(Lane* l, int n_events) {
   if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess)
     return fail(SGPU_EDEVICE, "hipStreamCreate failed");
   if (hipMalloc((void**)&l->queue, 256) != hipSuccess) return fail(SGPU_ENOMEM, "hipMalloc(queue) failed");
+  if (hipMemset(l->queue, 0, 256) != hipSuccess) return fail(SGPU_EDEVICE, "hipMemset(queue) failed");   // ([32]: the lane's sticky status word)
   for (int i = 0; i < n_events; ++i) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess) return fail(SGPU_EDEVICE, "hipEventCreate failed");
@@ -641,8 +642,24 @@ static bool hooks_on() {
   const char* v = env_get("SGPU_TEST_HOOKS");
   return v && *v && *v != '0';
 }
-static uint32_t hook_u32(const char* name, uint32_t dflt) { return hooks_on() ? env_u32(name, dflt) : dflt; }
-static const char* hook_get(const char* name) { return hooks_on() ? env_get(name) : nullptr; }
+// (a tool that sets a hook without the switch used to measure the default configuration in silence - the
+// library now says so, once per process)
+static void hook_ignored(const char* name) {
+  static std::atomic<bool> said{false};
+  const char* v = env_get(name);
+  if (v && *v && !said.exchange(true))
+    std::fprintf(stderr, "seismic_hip: %s is a test hook and is ignored unless SGPU_TEST_HOOKS=1 is set (further ignored hooks are not reported)\n", name);
+}
+static uint32_t hook_u32(const char* name, uint32_t dflt) {
+  if (hooks_on()) return env_u32(name, dflt);
+  hook_ignored(name);
+  return dflt;
+}
+static const char* hook_get(const char* name) {
+  if (hooks_on()) return env_get(name);
+  hook_ignored(name);
+  return nullptr;
+}
 
 // ---- host-side breakdown of a staged call (tools/latency_probe.py, sgpu_search_sequential) ----
 // A thread that sets call_timing() gets the wall time of every phase of its staged calls added up:
@@ -1141,8 +1158,8 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->block = NT;
   a->lds_bytes = (uint32_t)o;
   if (env_u32("SGPU_DEBUG", 0))
-    std::fprintf(stderr, "sgpu configure: NT %u lookup %u items_max %u dots_cap %u lists/group %u of %u uni %llu lds %llu\n", NT, lookup,
-                 items_max, dots_cap, qg, qc, (unsigned long long)uni, (unsigned long long)o);
+    std::fprintf(stderr, "sgpu configure: NT %u lookup %u items_max %u dots_cap %u lists/group %u of %u uni %llu lds %llu (ring of the streamed variant: %u bytes for 1024 slots)\n", NT, lookup,
+                 items_max, dots_cap, qg, qc, (unsigned long long)uni, (unsigned long long)o, stream_ring_bytes(1024));
   a->stream = lane->stream;
   a->qb.q_off = b->q_off;
   a->qb.q_comp = b->q_comp;
@@ -1166,7 +1183,9 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     a->qb.q_seed = b->q_order + b->nq;
   }
   a->qb.out_stats = mode != MODE_DOTS ? b->out_stats : nullptr;   // (null for staged batches: no work counters)
-  a->qb.status = b->staged ? b->status : nullptr;
+  // launch status word: a staged batch's travels back with its rows; a device-resident batch uses the lane's sticky word
+  // (queue + 32, zero from lane_init on; read after the rows by batch_fetch / batch_sync)
+  a->qb.status = b->staged ? b->status : lane->queue + 32;
   a->qb.done = nullptr;   // (set below for cooperative launches that write their rows to the host arena)
   a->qb.done_seq = 0;
   // cooperative variant wanted? (decided before the occupancy query: it is its own kernel symbol)
@@ -1183,10 +1202,28 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
         variant_built(NT, heap_variant(sp.k), false, true))   // (k > 256: the plain variant)
       a->coop.enabled = force ? 2u : 1u;
   }
+  // Streamed stage 2 (r06, search_kernel.inc "stage 2 as a stream"): plain search launches. The ring of item slots takes
+  // the union region the round loop's item tables would have: the largest power of two that fits (>= 256; the headline
+  // shape: 1024 slots in the 20 KB of 896 round-loop items). SGPU_STREAM=0 (test hook): the round loop.
+  a->streamed = 0;
+  a->p.ring = 0;
+  if (!a->coop.enabled && !a->counted && mode == MODE_SEARCH && dots_cap <= 65535u && hook_u32("SGPU_STREAM", 1) &&
+      variant_built(NT, heap_variant(sp.k), false, false, true)) {
+    const uint64_t uni_bytes = a->lds_bytes - a->L.uni;
+    uint32_t ring = std::min<uint32_t>(2048, std::max<uint32_t>(256, hook_u32("SGPU_RING_MAX", 2048)));
+    while (ring & (ring - 1)) ring &= ring - 1;   // (a power of two)
+    while (ring > 256 && stream_ring_bytes(ring) > uni_bytes) ring >>= 1;
+    if (stream_ring_bytes(ring) <= uni_bytes) {
+      a->streamed = 1;
+      a->p.ring = ring;
+      a->p.items_init = std::min<uint32_t>(a->p.items_init, ring);
+      a->p.items_min = std::min<uint32_t>(a->p.items_min, a->p.items_init);
+    }
+  }
   // occupancy of this kernel variant at this LDS size: queried once, then remembered
   int per_cu = 0;
   {
-    const uint64_t key = ((uint64_t)(a->coop.enabled != 0) << 58) | ((uint64_t)a->comp_width << 56) | ((uint64_t)a->counted << 55) | ((uint64_t)a->value_type << 52) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
+    const uint64_t key = ((uint64_t)(a->streamed != 0) << 59) | ((uint64_t)(a->coop.enabled != 0) << 58) | ((uint64_t)a->comp_width << 56) | ((uint64_t)a->counted << 55) | ((uint64_t)a->value_type << 52) | ((uint64_t)a->block << 40) | ((uint64_t)a->lookup << 36) |
                          ((uint64_t)heap_variant(a->p.k) << 28) | (uint64_t)(a->lds_bytes >> 4);
     auto it = d->occupancy.find(key);
     if (it == d->occupancy.end()) {
@@ -1330,6 +1367,10 @@ static void drain_events(Lane* l) {   // stream must be idle
 // judged on their own, and the variant stays off for this replica from then on (plain launches carry on).
 static sgpu_status coop_report(DeviceIndex* d, Lane* lane, uint32_t code) {
   if (!code) return SGPU_OK;
+  if (code >= 16) {   // streamed stage 2: a bounded wait of a role gave up (16 replayer, 17 feeder, 18 scorer)
+    (void)hipStreamSynchronize(lane->stream);
+    return fail(SGPU_EDEVICE, "search kernel (streamed stage 2): a bounded wait gave up (code %u)", code);
+  }
   if (lane->coop) (void)hipMemsetAsync(lane->coop + 64 + 12, 0, 4, lane->stream);
   (void)hipStreamSynchronize(lane->stream);
   if (!d->coop_broken) std::fprintf(stderr, "seismic_hip: cooperative search kernel reported protocol error %u on device %d; "
@@ -1338,8 +1379,13 @@ static sgpu_status coop_report(DeviceIndex* d, Lane* lane, uint32_t code) {
   return fail(SGPU_EDEVICE, "cooperative search kernel: protocol wait gave up (code %u)", code);
 }
 static sgpu_status coop_check_board(DeviceIndex* d, Lane* lane) {   // device-resident batches (not the latency path)
-  if (!lane->coop || !lane->coop_last) return SGPU_OK;
   uint32_t flag = 0;
+  HIP_TRY(hipMemcpy(&flag, lane->queue + 32, 4, hipMemcpyDeviceToHost));   // the lane's sticky status word (streamed variants)
+  if (flag) {
+    (void)hipMemset(lane->queue + 32, 0, 4);
+    return coop_report(d, lane, flag);
+  }
+  if (!lane->coop || !lane->coop_last) return SGPU_OK;
   HIP_TRY(hipMemcpy(&flag, lane->coop + 64 + 12, 4, hipMemcpyDeviceToHost));
   return coop_report(d, lane, flag);
 }
@@ -1617,7 +1663,7 @@ sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_
   }
   pc.lap(5);
   if (!b || b->nq == 0) return SGPU_OK;
-  if (lane->coop_last) {   // the launch's status word came back with the rows
+  {   // the launch's status word came back with the rows (cooperative protocol errors, bounded waits of the streamed variant)
     const sgpu_status cs = coop_report(d, lane, *(const volatile uint32_t*)(b->arena_host + b->status_off));
     if (cs != SGPU_OK) {
       lane->queue_dirty = true;

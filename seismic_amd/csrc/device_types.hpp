@@ -98,7 +98,7 @@ SGPU_HD inline uint32_t hash_slot(uint32_t c, uint32_t mult) {   // top bits of 
   return (uint32_t)(((uint64_t)(c & 0xffffffu) * mult) & 0xffffffffull) >> (32 - kHashBits);
 }
 enum { STATS_WORDS = 24 };
-enum { kStateWords = 160 };   // per-workgroup state words in LDS (ST_* in search_kernel.hip)   // per-query stats: 8 work counters + 12 phase clocks (>>4) + slot + pad
+enum { kStateWords = 160 };   // per-workgroup state words in LDS (ST_* in search_kernel.inc)   // per-query stats: 8 work counters + 12 phase clocks (>>4) + slot + pad
 
 // Cooperative mode (small launches, launch tails): workgroups that find the query queue empty do not
 // exit but HELP the workgroups that still own a query. An owner whose heap is full publishes one WIDE
@@ -156,7 +156,18 @@ struct KParams {
   uint32_t queue_base;   // value of the work counter when the launch starts (0 when the counter is zeroed per launch;
                          // latency-bound calls let it run on: a launch of nq queries on a grid of G workgroups takes
                          // exactly nq + G tickets, so the host knows where the next launch begins - no reset to enqueue)
+  uint32_t ring;         // streamed stage 2 (r06; search_kernel.inc "stage 2 as a stream"): item slots of the ring in
+                         // LDS, a power of two >= 256 (stream_ring_bytes of them fit the union region); 0 = the round loop
 };
+
+// Streamed stage 2 (r06): the union region then holds a RING of item slots {record ref / score 8 B, document 4 B, dot
+// index 2 B}, the two length-class queues of slot numbers (2 x 2 B per slot), one counter per 64-slot window and the
+// feeder's block tables (kStreamFeedPos positions x {inclusive item count 4 B, first posting 4 B, dot index 2 B}).
+#ifndef SGPU_STREAM_FEED_POS
+#define SGPU_STREAM_FEED_POS 192
+#endif
+enum { kStreamFeedPos = SGPU_STREAM_FEED_POS };   // positions per step of the feeder (a multiple of 64)
+SGPU_HD_EARLY inline uint32_t stream_ring_bytes(uint32_t ring) { return ring * 18u + ring / 16u + (uint32_t)kStreamFeedPos * 10u; }
 
 // The scoring loop's weights (q_sc, preceded by the 0.0 slot) sit at a FIXED offset of the dynamic LDS, so that the
 // scaled-byte dense lookup (search_kernel.inc: kScaledMaxNnz) can address them as `byte + constant`.
@@ -181,6 +192,7 @@ struct LaunchArgs {
   uint32_t lookup;  // LK_*: layout of the query lookup table in LDS
   uint32_t value_type; // SGPU_VAL_*: how the records store document values
   uint32_t counted; // 1: the accounting variant of the kernel (visited bitmap in HBM, exact work counters)
+  uint32_t streamed; // 1: the variant whose stage 2 is a stream (feeder / scorers / replayer wavefronts; KParams::ring)
   hipStream_t stream;
 };
 
@@ -194,8 +206,11 @@ inline uint32_t heap_variant(uint32_t k) { return k <= 64 ? 1u : (k <= 128 ? 2u 
 //   cooperative  512 threads: k <= 256;  1024 threads: k <= 128  (larger k: the plain variant)
 // 17 symbols per family (r04: 30, of which the k > 256 cooperative and 1024-thread ones spilled 190 - 230 VGPRs and
 // were never chosen by a benchmark configuration).
-inline bool variant_built(uint32_t block, uint32_t kr, bool counted, bool coop) {
+//   streamed     (r06) the plain variants once more, with stage 2 as a stream: 512 threads every k, 1024 threads k <= 128
+// 24 symbols per family.
+inline bool variant_built(uint32_t block, uint32_t kr, bool counted, bool coop, bool streamed = false) {
   if (block != 512 && block != 1024) return false;
+  if (streamed && (counted || coop)) return false;
   if (counted) return block == 512;
   if (block == 1024) return kr <= 2;
   return coop ? kr <= 4 : true;

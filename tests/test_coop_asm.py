@@ -28,7 +28,8 @@ def test_recorded_traffic_is_keyed_by_the_machine_code_it_was_measured_on():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench
     import kernel_code_id
-    ids = kernel_code_id.code_ids(pattern=r"seismic_search_kernel<unsigned short, 512, 1, 1, false, [012], false>")
+    # (r06: the timed variants are the streamed ones - a last template argument `true`)
+    ids = kernel_code_id.code_ids(pattern=r"seismic_search_kernel<unsigned short, 512, 1, 1, false, [012], false, true>")
     assert len(ids) == 3 and all(re.fullmatch(r"[0-9a-f]{16}", v) for v in ids.values()), ids
     pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["workloads"]
     keyed = {k: e for k, e in pm.items() if e.get("symbol_code_id")}

@@ -27,7 +27,7 @@ def test_forced_cooperative_path_on_the_fuzz_seeds(seed, monkeypatch):
     monkeypatch.setenv("SGPU_COOP_CHUNK_MIN", str([1, 4, 3, 7, 64][seed % 5]))
     if seed % 3 == 1:
         monkeypatch.setenv("SGPU_COOP_MAX_CAND", str([1, 4, 40][seed % 3]))   # rounds overflow: local rounds take over
-    _differential(seed, monkeypatch)
+    _differential(seed, "default", monkeypatch)
 
 
 def _shape(n_docs, n_postings, nq, seed=43):

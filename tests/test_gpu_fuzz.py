@@ -39,8 +39,13 @@ VALUE_LAWS = {
 }
 
 
+# (launches of 30 queries are cooperative ones by default - the round loop; "plain" switches that variant off, so the
+# same seeds run the plain variants: stage 2 as a stream, 1024-thread workgroups on even seeds, 512 on odd ones)
+@pytest.mark.parametrize("variant", ["default", "plain"])
 @pytest.mark.parametrize("seed", range(26))
-def test_differential(seed, monkeypatch):
+def test_differential(seed, variant, monkeypatch):
+    if variant == "plain":
+        monkeypatch.setenv("SGPU_COOP", "0")
     # small batches default to 1024-thread workgroups; odd seeds force the 512-thread configuration
     if seed % 2:
         monkeypatch.setenv("SGPU_BLOCK", "512")

@@ -14,13 +14,13 @@ def test_hashed_entries_on_the_fuzz_seeds(seed, monkeypatch):
     monkeypatch.setenv("SGPU_FORCE_HASH", "1")
     if seed % 3 == 0:
         monkeypatch.setenv("SGPU_COOP", "force")
-    _differential(seed, monkeypatch)
+    _differential(seed, "default", monkeypatch)
 
 
 @pytest.mark.parametrize("seed", [2, 9, 19])
 def test_without_the_hashed_entries(seed, monkeypatch):
     monkeypatch.setenv("SGPU_NO_HASH", "1")
-    _differential(seed, monkeypatch)
+    _differential(seed, "default", monkeypatch)
 
 
 @pytest.mark.parametrize("value_type", [0, 1, 2])

@@ -1,4 +1,5 @@
 #!/bin/bash
+export SGPU_TEST_HOOKS=1   # (the SGPU_* knobs these runs set are test hooks)
 # A/B of experiment builds of the library on the bench's kernel leg (run on the GPU box through gpurun):
 #   tools/ab_libs.sh <out-tag> "<lib suffixes, '' = the product library>" "<value types>" [extra bench args...]
 # e.g. tools/ab_libs.sh ab_s4 "default s4" "f16 fixedu8"     (libseismic_hip_s4.so from `make exp NAME=s4 EXTRA=...`)

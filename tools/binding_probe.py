@@ -3,6 +3,7 @@
 (1) in a fresh process, (2) after `import torch`, (3) after torch has initialised the device, (4) after request threads
 ran batch calls (bench.py's order), (5) after the oracle's OpenMP team ran. Native loop (sgpu_search_sequential) beside each."""
 import os, sys, time, threading
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,5 +1,7 @@
 """Host build time against the number of host threads: the default (hardware threads capped by the container's CPU quota,
 common.hpp host_threads) against explicit counts.   python tools/build_threads.py [n_docs] [counts, e.g. 0,256,64,16]"""
+import os
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from seismic_amd import _native

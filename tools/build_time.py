@@ -1,3 +1,5 @@
+import os
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import sys, time
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 from seismic_amd import _native

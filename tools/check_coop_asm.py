@@ -28,7 +28,9 @@ GOLD = os.path.join(ROOT, "profiles", "coop_asm_golden.json")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 # the variants the product launches for the benchmark shapes: u16 components, dense lookup, k <= 64, f16 / fixed-u8 /
 # DotVByte values, 512- and 1024-thread workgroups, cooperative
-WANT = re.compile(r"seismic_search_kernel<unsigned short, (512|1024), 1, 1, false, [012], true>")
+# (r06: the kernel template has one more parameter, STREAM, always false for the cooperative variants; the golden file keeps
+# the r05 names)
+WANT = re.compile(r"seismic_search_kernel<unsigned short, (512|1024), 1, 1, false, [012], true(?:, false)?>")
 
 
 def code_objects(lib):
@@ -69,7 +71,7 @@ def analyse(lib):
                                      capture_output=True, text=True).stdout
                 ins = [l.split("//")[0].strip() for l in asm.split("\n") if l.startswith("\t") or l.startswith(" ")]
                 ins = [i for i in ins if i]
-                key = WANT.search(d).group(0)
+                key = WANT.search(d).group(0).replace("true, false>", "true>")
                 res[key] = {
                     "instructions": len(ins),
                     "s_barrier": sum(i.startswith("s_barrier") for i in ins),

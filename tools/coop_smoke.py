@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Small stand-alone check of the cooperative kernel variant against the oracle (no pytest capture)."""
 import os, sys
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -4,6 +4,7 @@
   SGPU_LIB=seismic_amd/libseismic_hip_dbg.so SGPU_COOP_TRACE=1 python tools/coop_trace.py [n_docs] [n_queries]
 Event times are 10 ns ticks of the constant 100 MHz counter, printed in microseconds after the owner took its query."""
 import ctypes as C, os, sys
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -2,6 +2,7 @@
 """The tuned CPU oracle on the GPU box's host: thread sweep with the topology-aware pinning, before and after spreading the
 index's pages over the NUMA nodes.   python tools/cpu_ab.py [n_docs]"""
 import os, sys, time
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from seismic_amd import _native

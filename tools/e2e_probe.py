@@ -1,5 +1,6 @@
 """Throughput of sgpu_batch_search (host buffers in and out) from one and two request threads; SGPU_CHUNK_* knobs are honoured."""
 import os, sys, time, threading
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 sys.path.insert(0,'/root/repo')
 from seismic_amd import _native

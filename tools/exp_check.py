@@ -1,5 +1,6 @@
 """Rows of 2000 queries on the cached 8.8M-document index, saved to argv[1] (.npz): to compare an experiment build with the product."""
 import os, sys
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from seismic_amd import _native

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times Knn::new on the GPU (every document searched as a query through the search kernel)."""
 import os, sys, time
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from seismic_amd import _native

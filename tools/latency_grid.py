@@ -4,6 +4,7 @@ the library's rule, 0 = every slot of the chip). nq = 1: the reference's sequent
 through the binding (wall time per call, best of three passes).
   python tools/latency_grid.py [n_docs] [n_postings] [max_fraction] [query_cut]"""
 import os, sys, time
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

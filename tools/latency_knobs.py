@@ -4,6 +4,7 @@ index build, knobs changed in-process (the library re-reads SGPU_* when the envi
   python tools/latency_knobs.py [n_docs] [n_queries] [n_postings] [max_fraction] [query_cut] [short]
 (short: only the handful of combinations around the defaults)"""
 import itertools, os, sys
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

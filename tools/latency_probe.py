@@ -10,6 +10,7 @@ Prints, for the MS MARCO-shaped synthetic collection of n_docs documents:
   * the same loop through the Python binding (what a PyO3-style caller pays on top)
 """
 import json, os, sys, time
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

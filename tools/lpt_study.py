@@ -3,6 +3,7 @@
 (profiling build) against host-side features; simulated longest-first packing on the launch's workgroup slots under each
 ordering. Usage: SGPU_COOP=0 python tools/lpt_study.py [n_docs] [n_queries]"""
 import os, sys
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,5 +1,6 @@
 """Kernel time of mid-size launches (256 ... 2500 queries, or the sizes given) on the 8.8M-document shape; SGPU_COOP* knobs are honoured."""
 import os, sys, time
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from seismic_amd import _native

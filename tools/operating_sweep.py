@@ -15,6 +15,7 @@ appended to --out as it is measured; the last line holds, per recall target, the
 import argparse
 import json
 import os
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import sys
 import time
 

@@ -2,6 +2,7 @@
 """Per-phase clock breakdown of the search kernel (counters [8..19] of sgpu_batch_fetch_stats)."""
 import argparse
 import os
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import sys
 import time
 
@@ -70,6 +71,13 @@ for i, n in enumerate(NAMES):
     if i == 10:
         continue
     print("  %-22s %9.0f cyc  %5.1f%%" % (n, cyc[:, i].mean(), 100 * cyc[:, i].sum() / tot.sum()))
+if st[:, 21:24].any():   # (streamed stage 2, profiling build) polls of starved scorer wavefronts, of the blocked feeder, spans, budget
+    sp = st[:, 23].astype(np.int64)
+    sv = st[:, 21].astype(np.int64)
+    print("stream/query: starved scorer polls %.0f, blocked feeder polls %.0f, replayed spans %.1f (of which not read: %.1f), mean budget %.0f" % (
+        (sv & 0xfffff).mean(), st[:, 22].mean(), (sp >> 16).mean(), (sv >> 20).mean(), (sp & 0xffff).mean()))
+    print("  (streamed stage 2: filter+scan = skip test + tables + block lookup, postings+cut = posting loads + filing, phaseA = waiting for room,"
+          " phaseB = the final replay + rest, replay = windows replayed; all on the control wavefront)")
 print("work/query: blocks %.0f rows %.0f entries %.0f | scored blocks %.0f postings %.0f docs %.0f (spec %.0f)" % tuple(
     st[:, i].mean() for i in (0, 1, 2, 3, 4, 5, 7)))
 # per-slot busy time: queries per slot and sum

@@ -5,6 +5,7 @@ lists the query will walk, its length), once inside a 10 000-query launch and on
 The launch plan orders queries by an a-priori cost (make_plan in device_index.hip); this is the data that cost is fitted on.
 usage: proxy_probe.py OUT.npz [--docs N]"""
 import os
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import sys
 
 import numpy as np

@@ -4,6 +4,7 @@
 steady state against the pro-rata share of a 10 000-query call: the predicted strong-scaling efficiency at N GPUs.
   python tools/shard_probe.py [--docs 8800000] [--shards 1,2,4,8] [--threads 1,2,3]"""
 import argparse, os, sys, threading, time
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -2,6 +2,7 @@
 """Mid-size calls of sgpu_batch_search (host buffers in and out) with and without the cooperative tail launch
 (SGPU_TAIL_COOP = queries in the tail; abi.cpp search_shard): wall time per call, rows compared with the unsplit call."""
 import os, sys, time
+os.environ.setdefault("SGPU_TEST_HOOKS", "1")   # (the SGPU_* knobs and sgpu_debug_* entry points this tool drives are test hooks)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
