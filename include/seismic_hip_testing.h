@@ -23,6 +23,9 @@ sgpu_status sgpu_debug_row_dir(const sgpu_index* idx, uint32_t* out, uint64_t ca
 /* the launch plan of a batch: processing order, out3 = {block dots needed at most, largest first list, largest list} */
 sgpu_status sgpu_debug_plan(const sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals,
                             uint32_t nq, uint32_t query_cut, uint32_t* order_out, uint32_t* out3);
+/* the same plan as the DEVICE computes it for staged chunks (needs an uploaded index; 1 ... 16384 queries, query_cut 1 ... 16) */
+sgpu_status sgpu_debug_device_plan(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals,
+                                   uint32_t nq, uint32_t query_cut, uint32_t* order_out, uint32_t* out3);
 /* the calling thread's staged calls add their host-side phase times to buf8[0..7] from now on (NULL: off) */
 void sgpu_debug_call_timing(double* buf8);
 /* timeline of the last cooperative launch (trace builds) */

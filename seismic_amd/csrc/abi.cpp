@@ -43,6 +43,9 @@ sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
 int device_count();
 double*& call_timing();
+bool device_plan_applies(const DeviceIndex* d, const sgpu_search_params& sp);
+sgpu_status debug_device_plan(DeviceIndex* d, const uint64_t* q_off, const uint32_t* comps, const float* vals, uint32_t nq,
+                              uint32_t query_cut, uint32_t* order_out, uint32_t* out3);
 sgpu_status debug_plan(const HostIndex& h, const uint64_t* q_off, const uint32_t* comps, const float* vals, uint32_t nq,
                        uint32_t query_cut, uint32_t* order_out, uint32_t* out3);
 uint32_t coop_trace_dump(DeviceIndex* d, uint64_t* out, uint32_t cap);
@@ -365,7 +368,10 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
     explicit InFlight(DeviceIndex* d_) : d(d_), shared(call_enter(d_)) {}
     ~InFlight() { call_exit(d); }
   } in_flight(d);
-  const uint32_t chunk_max = chunk_max_env ? chunk_max_env : (in_flight.shared ? 2u : 4u);
+  // (r06: with the launch plan computed on the device - plan_kernel.hip - a chunk's host side is validation and a copy,
+  // ~20 us per 1000 queries: two chunks whoever else is calling - one request thread 1.61 M queries/s against 1.59 / 1.54 M
+  // with four / one, two threads 1.71 against 1.69 / 1.68; profiles/r06_entry_point_chunks.txt)
+  const uint32_t chunk_max = chunk_max_env ? chunk_max_env : ((in_flight.shared || device_plan_applies(d, params)) ? 2u : 4u);
   Job jobs[8];
   // Mid-size shards (SGPU_TAIL_COOP = n, an experiment, off by default): more queries than the cooperative variant takes
   // on its own, fewer than two chunks - the last n queries go out as a second launch on another lane, small enough for
@@ -634,6 +640,14 @@ sgpu_status sgpu_debug_plan(const sgpu_index* idx, const uint64_t* q_off, const 
   SGPU_HOOK_OR(SGPU_EINVAL);
   if (!idx || !q_off || !order_out || !out3) return fail(SGPU_EINVAL, "null argument");
   return debug_plan(idx->host, q_off, comps, vals, nq, query_cut, order_out, out3);
+}
+
+// (not part of the boundary: the same plan as the DEVICE computes it for staged chunks - plan_kernel.hip; replica 0)
+sgpu_status sgpu_debug_device_plan(sgpu_index* idx, const uint64_t* q_off, const uint32_t* comps, const float* vals, uint32_t nq,
+                                   uint32_t query_cut, uint32_t* order_out, uint32_t* out3) {
+  SGPU_HOOK_OR(SGPU_EINVAL);
+  if (!idx || !q_off || !order_out || !out3) return fail(SGPU_EINVAL, "null argument");
+  return debug_device_plan(idx->dev, q_off, comps, vals, nq, query_cut, order_out, out3);
 }
 
 // (not part of the boundary: the calling thread's staged calls add the wall time of their host-side phases to

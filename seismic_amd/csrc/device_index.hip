@@ -125,6 +125,10 @@ struct DeviceIndex {
   Lane main;
   Lane pool[kPool];
   std::unordered_map<uint64_t, int> occupancy;   // kernel variant + LDS size -> workgroups per CU
+  // Device-side launch plans (plan_kernel.hip): per query_cut, the largest number of block dots a query of an EARLIER chunk
+  // needed (all its lists) - what the LDS layout of the next chunk is sized for; a query that needs more walks its lists in
+  // groups. Seeded by the first chunk's host plan, raised by what every device plan reports back with its rows. (mu)
+  std::unordered_map<uint32_t, uint32_t> plan_dots_seen;
   std::mutex mu;        // main lane, occupancy cache
   std::atomic<uint32_t> calls_inflight{0};               // entry-point calls on this replica right now (call_enter / call_exit)
   std::atomic<int64_t> concurrent_seen_us{-((int64_t)1 << 60)};   // when two of them were last seen together
@@ -591,6 +595,8 @@ struct sgpu_batch {
   uint32_t queue_base = 0;             // KParams::queue_base of the next launch
   size_t arena_cap = 0, in_bytes = 0, out_off = 0, out_bytes = 0;
   uint32_t* queue_dev = nullptr;
+  uint32_t device_plan_cut = 0xffffffffu;   // the chunk's launch plan was computed on the device for this query_cut (its
+                                            //   maxima come back in words 1 - 3 of the status block); 0xffffffff: host plan
 };
 
 namespace sgpu {
@@ -813,6 +819,7 @@ sgpu_status batch_create(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_
 }
 
 const DeviceIndex* batch_replica(const sgpu_batch* b) { return b ? b->owner : nullptr; }
+static inline size_t al16_(size_t x) { return (x + 15) & ~(size_t)15; }
 
 // Which lists each query will walk (the device applies the same rule: query_cut heaviest
 // components by f32::total_cmp, ties by ascending component), hence how many block dots it
@@ -955,6 +962,46 @@ sgpu_status debug_plan(const HostIndex& h, const uint64_t* q_off, const uint32_t
   return SGPU_OK;
 }
 
+// Will chunks of a call with these parameters be planned on the device (once a first chunk has seeded the cache)? abi.cpp
+// then cuts a call into fewer chunks: there is no host-side planning left to hide behind the previous chunk's kernel.
+bool device_plan_applies(const DeviceIndex* d, const sgpu_search_params& sp) {
+  const bool hash_family = d->comp_width == 4 && d->value_type == SGPU_VAL_F16 && d->view.dim < (1u << 24);
+  const char* v = std::getenv("SGPU_DEVICE_PLAN");
+  return sp.query_cut >= 1 && sp.query_cut <= kDevicePlanCutMax && !sp.first_sorted && !hash_family && !(v && *v == '0');
+}
+
+// (test hook: the DEVICE's launch plan of a batch - plan_kernel.hip - in the terms of debug_plan: order, out3 = {block dots
+// a query needs at most, largest list walked first, largest list walked}. sgpu_debug_device_plan, tests/test_gpu_boundary.py)
+sgpu_status debug_device_plan(DeviceIndex* d, const uint64_t* q_off, const uint32_t* comps, const float* vals, uint32_t nq,
+                              uint32_t query_cut, uint32_t* order_out, uint32_t* out3) {
+  if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device");
+  if (nq == 0 || nq > kDevicePlanMaxQueries || query_cut == 0 || query_cut > kDevicePlanCutMax)
+    return fail(SGPU_EINVAL, "the device plans 1 ... %u queries at query_cut 1 ... %u", (unsigned)kDevicePlanMaxQueries, (unsigned)kDevicePlanCutMax);
+  HIP_TRY(hipSetDevice(d->device));
+  const uint64_t nnz = q_off[nq];
+  uint32_t n2 = 2;
+  while (n2 < nq) n2 <<= 1;
+  std::vector<uint32_t> off32((size_t)nq + 1);
+  for (uint32_t q = 0; q <= nq; ++q) off32[q] = (uint32_t)q_off[q];
+  const size_t o_comp = al16_((size_t)(nq + 1) * 4), o_val = o_comp + al16_(nnz * 4), o_keys = o_val + al16_(nnz * 4),
+               o_max = o_keys + (size_t)n2 * 8, o_order = o_max + 16, total = o_order + (size_t)nq * 4;
+  uint8_t* buf = nullptr;
+  if (hipMalloc((void**)&buf, total) != hipSuccess) return fail(SGPU_ENOMEM, "hipMalloc of %zu bytes failed", total);
+  hipError_t e = hipMemcpy(buf, off32.data(), (size_t)(nq + 1) * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && nnz) e = hipMemcpy(buf + o_comp, comps, nnz * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && nnz) e = hipMemcpy(buf + o_val, vals, nnz * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(buf + o_max, 0, 16);
+  if (e == hipSuccess)
+    e = launch_device_plan(d->view, (const uint32_t*)buf, (const uint32_t*)(buf + o_comp), (const float*)(buf + o_val), nq, query_cut,
+                           (uint64_t*)(buf + o_keys), (uint32_t*)(buf + o_max), (uint32_t*)(buf + o_order), d->main.stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(d->main.stream);
+  if (e == hipSuccess) e = hipMemcpy(order_out, buf + o_order, (size_t)nq * 4, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(out3, buf + o_max, 12, hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  if (e != hipSuccess) return fail(SGPU_EDEVICE, "device plan failed: %s", hipGetErrorString(e));
+  return SGPU_OK;
+}
+
 static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, const sgpu_batch_plan** out) {
   for (const auto& pl : b->plans)
     if (pl.query_cut == query_cut) {
@@ -1077,7 +1124,31 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
                         !hook_u32("SGPU_NO_DENSE", 0) && searching;
   const uint64_t split_bits = up((uint64_t)words * 4), split_bytes = split_bits + up((uint64_t)words * 2);
   // the round's item tables shrink (down to 256 items) if that is what keeps 2 workgroups per CU
-  auto uni_for = [&](uint32_t items) { return up(std::max<uint64_t>((uint64_t)items * 16 + NT * 12, sort_bytes)); };
+  // Streamed stage 2 (r06, search_kernel.inc "stage 2 as a stream"): plain search launches (the cooperative variant - small
+  // launches - and the counted pass keep the round loop). Its union region holds a RING of item slots, a power of two: the
+  // fitting loops below step `items` down by 128 as they always did; for a streamed launch 1024 items mean a ring of 1024
+  // slots (20.4 KB where the round loop's tables of 1024 items take 22.5), anything from 512 on one of 512, less 256.
+  // SGPU_STREAM=0 (test hook): the round loop.
+  const bool coop_wanted = [&] {
+    const char* cm = env_get("SGPU_COOP");
+    const bool force = cm && !std::strcmp(cm, "force");
+    const bool off = (cm && !std::strcmp(cm, "0")) || d->coop_broken;
+    return !off && !want_counted && mode == MODE_SEARCH && (force || b->nq <= env_u32("SGPU_COOP_MAX_NQ", d->n_cu)) &&
+           variant_built(NT, heap_variant(sp.k), false, true);
+  }();
+  const bool stream_wanted = !coop_wanted && !want_counted && mode == MODE_SEARCH && hook_u32("SGPU_STREAM", 1) &&
+                             variant_built(NT, heap_variant(sp.k), false, false, true);
+  const uint32_t ring_cap = [&] {
+    uint32_t r = std::min<uint32_t>(1024, std::max<uint32_t>(256, hook_u32("SGPU_RING_MAX", 1024)));
+    while (r & (r - 1)) r &= r - 1;
+    return r;
+  }();
+  auto ring_of = [&](uint32_t items) { return std::min<uint32_t>(ring_cap, items >= 1024 ? 1024u : (items >= 512 ? 512u : 256u)); };
+  auto uni_for = [&](uint32_t items) {
+    if (stream_wanted)   // (+ room for the item tables of a kNN refinement round of at least 128 items, which uses the same region)
+      return up(std::max<uint64_t>(std::max<uint64_t>(stream_ring_bytes(ring_of(items)), 128 * 16 + NT * 12), sort_bytes));
+    return up(std::max<uint64_t>((uint64_t)items * 16 + NT * 12, sort_bytes));
+  };
   const uint64_t smallest_lookup = (d->comp_width == 4) ? split_bytes : bitmap_bytes;
   const uint32_t want_items = items_max;
   if (!hook_get("SGPU_ITEMS_MAX")) {
@@ -1145,6 +1216,10 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->p.mode = mode == MODE_COUNTED ? (uint32_t)MODE_SEARCH : mode;
   a->p.n_knn = mode == MODE_DOTS ? 0u : sp.n_knn;   // ignored when the index has no graph, as the reference does
   a->counted = want_counted ? 1u : 0u;
+  // (a streamed launch: the ring the region was sized for; items_max is then what is left for the item tables of a kNN
+  // refinement round in the same region)
+  const uint32_t ring = stream_wanted ? ring_of(items_max) : 0u;
+  if (stream_wanted) items_max = std::max<uint32_t>(128, std::min<uint32_t>(1024, (uint32_t)((uni - NT * 12) / 16) & ~127u));
   a->p.items_max = items_max;
   a->p.items_init = std::min<uint32_t>(items_max, hook_u32("SGPU_ITEMS_INIT", 128));
   a->p.items_min = std::min<uint32_t>(a->p.items_init, hook_u32("SGPU_ITEMS_MIN", 64));
@@ -1158,8 +1233,8 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->block = NT;
   a->lds_bytes = (uint32_t)o;
   if (env_u32("SGPU_DEBUG", 0))
-    std::fprintf(stderr, "sgpu configure: NT %u lookup %u items_max %u dots_cap %u lists/group %u of %u uni %llu lds %llu (ring of the streamed variant: %u bytes for 1024 slots)\n", NT, lookup,
-                 items_max, dots_cap, qg, qc, (unsigned long long)uni, (unsigned long long)o, stream_ring_bytes(1024));
+    std::fprintf(stderr, "sgpu configure: nq %u NT %u lookup %u items_max %u ring %u dots_cap %u lists/group %u of %u uni %llu lds %llu\n", b->nq, NT, lookup,
+                 items_max, ring, dots_cap, qg, qc, (unsigned long long)uni, (unsigned long long)o);
   a->stream = lane->stream;
   a->qb.q_off = b->q_off;
   a->qb.q_comp = b->q_comp;
@@ -1202,23 +1277,14 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
         variant_built(NT, heap_variant(sp.k), false, true))   // (k > 256: the plain variant)
       a->coop.enabled = force ? 2u : 1u;
   }
-  // Streamed stage 2 (r06, search_kernel.inc "stage 2 as a stream"): plain search launches. The ring of item slots takes
-  // the union region the round loop's item tables would have: the largest power of two that fits (>= 256; the headline
-  // shape: 1024 slots in the 20 KB of 896 round-loop items). SGPU_STREAM=0 (test hook): the round loop.
+  // streamed stage 2: decided with the LDS layout above (stream_wanted); the cooperative decision just made must agree
   a->streamed = 0;
   a->p.ring = 0;
-  if (!a->coop.enabled && !a->counted && mode == MODE_SEARCH && dots_cap <= 65535u && hook_u32("SGPU_STREAM", 1) &&
-      variant_built(NT, heap_variant(sp.k), false, false, true)) {
-    const uint64_t uni_bytes = a->lds_bytes - a->L.uni;
-    uint32_t ring = std::min<uint32_t>(2048, std::max<uint32_t>(256, hook_u32("SGPU_RING_MAX", 2048)));
-    while (ring & (ring - 1)) ring &= ring - 1;   // (a power of two)
-    while (ring > 256 && stream_ring_bytes(ring) > uni_bytes) ring >>= 1;
-    if (stream_ring_bytes(ring) <= uni_bytes) {
-      a->streamed = 1;
-      a->p.ring = ring;
-      a->p.items_init = std::min<uint32_t>(a->p.items_init, ring);
-      a->p.items_min = std::min<uint32_t>(a->p.items_min, a->p.items_init);
-    }
+  if (stream_wanted && !a->coop.enabled && dots_cap <= 65535u && stream_ring_bytes(ring) <= a->lds_bytes - a->L.uni) {
+    a->streamed = 1;
+    a->p.ring = ring;
+    a->p.items_init = std::min<uint32_t>(std::min<uint32_t>(hook_u32("SGPU_ITEMS_INIT", 128), 1024), ring);
+    a->p.items_min = std::min<uint32_t>(a->p.items_min, a->p.items_init);
   }
   // occupancy of this kernel variant at this LDS size: queried once, then remembered
   int per_cu = 0;
@@ -1576,8 +1642,38 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   } catch (const std::bad_alloc&) {
     return fail(SGPU_ENOMEM, "out of host memory planning a query batch");
   }
-  st = make_plan(d, q_off, comps, vals, nq, cut, &b->plans.back());
-  if (st != SGPU_OK) return st;
+  // The launch plan: on the DEVICE for chunks of 256 ... 16384 queries once a first chunk has told what this index and
+  // query_cut need (r06, plan_kernel.hip: the calling thread no longer spends ~0.2 us per query on it - a third of a
+  // one-thread call); on the host for small chunks (microseconds), for the first chunk, for a sorted first list (its
+  // sort buffer must hold the chunk's largest first list: the host plan knows it exactly), for query_cut > 16 and for the
+  // hashed lookup of u32 indexes (per-query seeds). SGPU_DEVICE_PLAN=0: always the host.
+  b->device_plan_cut = 0xffffffffu;
+  {
+    const bool hash_family = d->comp_width == 4 && d->value_type == SGPU_VAL_F16 && d->view.dim < (1u << 24);
+    uint32_t seen = 0;
+    if (nq >= kDevicePlanMinQueries && nq <= kDevicePlanMaxQueries && cut >= 1 && cut <= kDevicePlanCutMax && !sp.first_sorted &&
+        !hash_family && env_u32("SGPU_DEVICE_PLAN", 1) && !hook_u32("SGPU_NO_LPT", 0) && !hook_u32("SGPU_AFFINITY_CLASSES", 0)) {
+      std::lock_guard<std::mutex> lock(d->mu);
+      auto it = d->plan_dots_seen.find(cut);
+      if (it != d->plan_dots_seen.end()) seen = it->second;
+    }
+    if (seen) {
+      sgpu_batch_plan& pl = b->plans.back();
+      pl.query_cut = cut;
+      pl.dots_cap = std::max(seen, std::max<uint32_t>(d->max_nb, 1));
+      pl.max_nb = 0;
+      pl.max_list_nb = std::max<uint32_t>(d->max_nb, 1);   // (no list of the index has more blocks: a bound, not the chunk's maximum)
+      pl.hash_ok = false;
+      pl.order.clear();
+      b->device_plan_cut = cut;
+    } else {
+      st = make_plan(d, q_off, comps, vals, nq, cut, &b->plans.back());
+      if (st != SGPU_OK) return st;
+      std::lock_guard<std::mutex> lock(d->mu);
+      uint32_t& v = d->plan_dots_seen[cut];
+      v = std::max(v, b->plans.back().dots_cap);
+    }
+  }
   pc.lap(0);
   uint8_t* hs = b->arena_host;
   std::memset(hs, 0, 16);
@@ -1587,7 +1683,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     std::memcpy(hs + o_comp, comps, nnz * 4);
     std::memcpy(hs + o_val, vals, nnz * 4);
   }
-  std::memcpy(hs + o_order, b->plans.back().order.data(), (size_t)nq * 8);
+  if (b->device_plan_cut == 0xffffffffu) std::memcpy(hs + o_order, b->plans.back().order.data(), (size_t)nq * 8);
   std::memset(hs + o_status, 0, 16);
   std::memset(hs + o_fix, 0, 16);
   // A latency-bound call (a handful of queries) has the kernel write its few result rows straight into the pinned
@@ -1625,6 +1721,13 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     b->queue_base = lane->queue_pos;
   } else {
     HIP_TRY(hipMemcpyAsync(b->arena_dev, hs, in_bytes, hipMemcpyHostToDevice, lane->stream));
+    if (b->device_plan_cut != 0xffffffffu) {
+      // order -> the arena's order region; the maxima -> words 1 - 3 of the status block (zeroed by the copy above, they
+      // come back with the rows); the sort keys borrow the output region, which the search kernel overwrites afterwards
+      // (16 bytes per query at least: room for the <= 2 nq keys)
+      HIP_TRY(launch_device_plan(d->view, b->q_off, b->q_comp, b->q_val, nq, cut, (uint64_t*)(b->arena_dev + r_n),
+                                 (uint32_t*)(b->arena_dev + o_status) + 1, b->q_order, lane->stream));
+    }
   }
   pc.lap(2);
   // from here on a failure waits for the stream: the lane (and its pinned arena) goes back to the pool
@@ -1669,6 +1772,12 @@ sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_
       lane->queue_dirty = true;
       return cs;
     }
+  }
+  if (b->device_plan_cut != 0xffffffffu) {   // what this chunk's queries needed: the next chunks' LDS layouts are sized for it
+    const uint32_t need = ((const volatile uint32_t*)(b->arena_host + b->status_off))[1];
+    std::lock_guard<std::mutex> lock(d->mu);
+    uint32_t& v = d->plan_dots_seen[b->device_plan_cut];
+    v = std::max(v, need);
   }
   const size_t nq = b->nq, k = b->k_max;
   const uint8_t* r = b->arena_host + b->out_off;

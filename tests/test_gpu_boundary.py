@@ -221,3 +221,38 @@ def test_large_batches_are_pipelined_in_chunks(monkeypatch):
     for t_ in th:
         t_.join()
     assert not errors, errors
+
+
+def test_the_device_plans_a_chunk_as_the_host_does(monkeypatch):
+    """r06: the launch plan of a staged chunk (processing order, block dots a query needs) is computed on the device
+    (plan_kernel.hip) once a first chunk has told what the index needs. The device's order is the host's (make_plan:
+    longest expected first, ties in input order) bit for bit, its maxima are the host's; chunks planned on the device, on
+    the host (SGPU_DEVICE_PLAN=0) and with an LDS layout sized for LESS than a later chunk needs (lists then walked in
+    groups) return the oracle's rows."""
+    import ctypes
+    ix, dim = _index(81, 9000, 700)
+    ix.upload(0)
+    q_off, qc, qv = random_queries(82, 3000, dim, 1, 60)
+    L = _native.lib()
+    sig = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    L.sgpu_debug_plan.argtypes = sig
+    L.sgpu_debug_device_plan.argtypes = sig
+    p = lambda x: x.ctypes.data_as(ctypes.c_void_p)   # noqa: E731
+    for nq in (1, 2, 255, 1000, 3000):
+        for cut in (1, 4, 16):
+            ho, h3 = np.zeros(nq, np.uint32), np.zeros(3, np.uint32)
+            do, d3 = np.zeros(nq, np.uint32), np.zeros(3, np.uint32)
+            assert L.sgpu_debug_plan(ix.h, p(q_off), p(qc), p(qv), nq, cut, p(ho), p(h3)) == 0
+            assert L.sgpu_debug_device_plan(ix.h, p(q_off), p(qc), p(qv), nq, cut, p(do), p(d3)) == 0
+            assert np.array_equal(ho, do), (nq, cut)
+            # (the host reports at least 1 for its two sizes, the device the plain maxima)
+            assert (max(int(d3[0]), 1), int(d3[1]), max(int(d3[2]), 1)) == (int(h3[0]), int(h3[1]), int(h3[2])), (nq, cut, h3, d3)
+    q = (q_off, qc, qv)
+    exp = orc.batch_search(ix.desc, *q, 10, 6, 0.9, False)[:3]
+    # first call: a short chunk of few, short queries seeds the cache low; the big call then meets queries that need more
+    few = random_queries(83, 300, dim, 1, 2)
+    _same(ix.batch_search(*few, 10, 6, 0.9, False), orc.batch_search(ix.desc, *few, 10, 6, 0.9, False)[:3])
+    for _ in range(3):   # (device plans from the second chunk on; the cache grows to what the chunks report)
+        _same(ix.batch_search(*q, 10, 6, 0.9, False), exp)
+    monkeypatch.setenv("SGPU_DEVICE_PLAN", "0")
+    _same(ix.batch_search(*q, 10, 6, 0.9, False), exp)
