@@ -565,6 +565,11 @@ def main():
         "timing_s": {"generate": t_gen, "build": t_build, "upload": t_up},
     }
     if world > 1:
+        # every rank's kernel leg (its shard resident in HBM, HIP events): the first 8-GPU run shows at once whether a GPU lags
+        t = torch.zeros(world, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        t[rank] = kernel_ms
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        out["kernel_ms_per_rank"] = [round(float(x), 4) for x in t.tolist()]
         out["value_is"] = ("pipelined: the K sharded batches are issued back to back from %d request thread(s) per rank, so "
                            "calls of consecutive batches overlap on a GPU" % n_threads)
         out["host_threads_per_rank_for_host_phases"] = os.environ.get("SGPU_HOST_THREADS")

@@ -332,7 +332,7 @@ sgpu_status build_host_index(uint32_t comp_width, uint64_t n_docs, uint64_t dim,
                              const void* comps_in, const float* vals, const sgpu_build_config& cfg,
                              HostIndex* out) {
   if (comp_width != 2 && comp_width != 4) return fail(SGPU_EINVAL, "comp_width must be 2 or 4");
-  if (dim == 0 || (comp_width == 2 && dim > 65536)) return fail(SGPU_EINVAL, "dim out of range for comp_width");
+  if (dim == 0 || (comp_width == 2 && dim > 65535)) return fail(SGPU_EINVAL, "dim out of range for comp_width (u16 components: at most 65535; use comp_width 4)");
   if (n_docs > 0x7fffffffull) return fail(SGPU_EINVAL, "too many documents");
   if (cfg.n_postings == 0 || cfg.doc_cut == 0) return fail(SGPU_EINVAL, "n_postings and doc_cut must be > 0");
   if (!offsets || offsets[0] != 0) return fail(SGPU_EINVAL, "offsets[0] != 0");

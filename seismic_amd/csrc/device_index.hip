@@ -436,7 +436,8 @@ sgpu_status device_index_upload(const HostIndex& h, int device, DeviceIndex** ou
         std::vector<uint32_t> dir;
         uint32_t n_buckets = 0;
         if (!pack_row_dir(h, mid, &dir, &n_buckets))
-          return bail(fail(SGPU_ELIMIT, "the summary rows of this index do not fit the row directory (u16 components need dim <= 65535)"));
+          return bail(fail(SGPU_ELIMIT, h.dim > 65535 ? "u16 components need dim <= 65535 for the device's row directory"
+                                                       : "the index has too many summary rows for the device's row directory (2^31 buckets)"));
         static_assert(sizeof(d->view.row_dir) == sizeof(const uint32_t*), "pointer field");
         if ((st = dev_copy(d, dir.data(), dir.size(), (const uint32_t**)&d->view.row_dir)) != SGPU_OK) return bail(st);
         d->view.row_dir_buckets = n_buckets;
@@ -1614,7 +1615,9 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     b->owner = d;
     // twice the need: a lane that has served one chunk of a call cut in four also holds a chunk of a call cut in two (the
     // number of chunks follows the load of the replica, abi.cpp) - no pinned reallocation in the middle of a stream of calls
-    b->arena_cap = std::max<size_t>(total * 5 / 2, 1 << 16);   // (2.5 x: chunks of one call differ by a few per cent in components)
+    // (2.5 x: chunks of one call differ by a few per cent in components; the slack is bounded - the arena exists twice, in
+    // HBM and as pinned host memory, per lane: ADVICE r05)
+    b->arena_cap = std::max<size_t>(std::min<size_t>(total * 5 / 2, total + ((size_t)64 << 20)), 1 << 16);
     if (hipMalloc((void**)&b->arena_dev, b->arena_cap) != hipSuccess ||
         hipHostMalloc((void**)&b->arena_host, b->arena_cap, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {   // (fine-grained by request, not by the runtime's default: the kernel's rows and done word must be visible as they land)
       batch_free(b);

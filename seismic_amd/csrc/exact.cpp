@@ -41,7 +41,9 @@ sgpu_status exact_search_host(const HostIndex& ix, const uint64_t* q_off, const 
     std::vector<uint32_t> idoc(nnz);
     std::vector<float> ival(nnz);   // document values widened once (exact for f16 and fixed-u8)
     {
-      const int bt = nt < 1 ? 1 : nt;
+      // (the per-thread counters are threads x vocabulary 64-bit words: the team is cut down so that they stay under 256 MB -
+      // a 1M-id vocabulary on 128 threads asked for 1 GB of scratch where the serial pass needs 8 MB)
+      const int bt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(nt < 1 ? 1 : nt), ((uint64_t)256 << 20) / (8 * std::max<uint64_t>(ix.dim, 1))));
       std::vector<uint64_t> cur((size_t)bt * ix.dim, 0);   // [thread][component]: count, then first slot
       auto range = [&](int t, uint64_t* d0, uint64_t* d1) {
         *d0 = ix.n_docs * (uint64_t)t / (uint64_t)bt;

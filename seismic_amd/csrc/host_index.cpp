@@ -110,7 +110,10 @@ sgpu_status validate_desc(const sgpu_index_desc& d) {
     int e = 0;
     if (!(d.val_scale > 0.0f) || std::frexp(d.val_scale, &e) != 0.5f) return fail(SGPU_EINVAL, "val_scale must be a positive power of two");
   }
-  if (d.comp_width == 2 && d.dim > 65536) return fail(SGPU_EINVAL, "dim %llu does not fit u16 components", (unsigned long long)d.dim);
+  // (65535, not 65536: the records pad with the sentinel id `dim` and the device's row directory keys a row by
+  // list << 16 | component with 0xffffffff as its empty marker - an index of 65536 u16 ids could be built and saved but not
+  // uploaded; ADVICE r05. Use u32 components for such a vocabulary.)
+  if (d.comp_width == 2 && d.dim > 65535) return fail(SGPU_EINVAL, "dim %llu does not fit u16 components (at most 65535; use comp_width 4)", (unsigned long long)d.dim);
   if (d.dim > 0xffffffffull || d.n_docs > 0x7fffffffull) return fail(SGPU_EINVAL, "dim/n_docs out of range");
   if (!d.fwd_offsets || !d.list_block_start || !d.block_post_start || !d.list_row_start || !d.row_ptr)
     return fail(SGPU_EINVAL, "null offset array in descriptor");

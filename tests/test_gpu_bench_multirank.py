@@ -51,6 +51,7 @@ def test_two_ranks_strong_scaling_is_the_single_gpu_answer(tmp_path):
     # one batch at a time (a barrier around every step, one call per rank)
     assert "pipelined" in out["value_is"]
     assert out["value_one_batch_at_a_time"] > 0 and out["one_batch_at_a_time"]["ms_per_step"] > 0
+    assert len(out["kernel_ms_per_rank"]) == out["n_gpus"] and all(x > 0 for x in out["kernel_ms_per_rank"])   # (r06)
     assert int(out["host_threads_per_rank_for_host_phases"]) >= 1
 
 

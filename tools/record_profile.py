@@ -16,7 +16,11 @@ pmc_line = json.loads(open(os.path.join(src, "pmc_FETCH_SIZE.json")).read().stri
 def timed_kernel(table):
     best = None
     for k, c in table.items():
-        if k.startswith("seismic_search_kernel") and ", false," in k.split(">")[0] and not k.rstrip(">").endswith("true"):
+        if not k.startswith("seismic_search_kernel<"):
+            continue
+        # template arguments: component type, threads, heap registers, lookup, COUNTED, value type, COOP[, STREAM (r06)]
+        targs = [x.strip() for x in k[k.index("<") + 1:k.rindex(">")].split(",")]
+        if targs[4] == "false" and targs[6] == "false":   # the timed variants: neither the counted pass nor a cooperative launch
             d = next(iter(c.values()))["dispatches"]
             if best is None or d > best[1]:
                 best = (k, d)
@@ -29,6 +33,15 @@ ent = {"traffic_bytes": int(2 * f["mean"] * 1024 + w["mean"] * 1024), "fetch_siz
        "dispatches": f["dispatches"], "kernel_source_id": pmc_line["roofline"]["kernel_source_id"],
        "algorithmic_bytes": line["roofline"]["algorithmic_bytes_per_launch"]}
 ent["ratio"] = round(ent["traffic_bytes"] / ent["algorithmic_bytes"], 4) if ent["algorithmic_bytes"] else None
+# the symbol the counter passes ran and the identity of its machine code in the library of this tree (the one that ran:
+# the .so travels to the GPU box with the snapshot) - bench.py reports the figure for that code only
+ent["symbol"] = K
+try:
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_code_id
+    ent["symbol_code_id"] = kernel_code_id.code_ids(None, r"seismic_search_kernel<").get(K.replace("seismic_search_kernel", ""))
+except Exception as e:   # noqa: BLE001
+    print("record_profile: no machine-code id (%r)" % (e,), file=sys.stderr)
 pm = json.load(open(os.path.join(P, "pmc_traffic.json")))
 key = pmc_line["config"]["workload_key"]
 if mode == "traffic":
