@@ -1022,6 +1022,18 @@ static sgpu_status plan_for(DeviceIndex* d, sgpu_batch* b, uint32_t query_cut, c
   return SGPU_OK;
 }
 
+// Which launch sizes take the cooperative variant on their own. Until r05: up to n_cu queries. With the streamed plain
+// variants the picture has two windows (r06, 8.8M documents, kernel us per launch, cooperative / plain - profiles/
+// r06_small_launches.txt): 144 queries 304 / 326, 176: 327 / 329, 224: 351 / 339, 256: 365 / 340 - one 1024-thread streamed
+// workgroup per CU beats the helpers once most CUs own a query; 288: 420 / 453, 352: 448 / 473, 416: 481 / 512, 448: 496 / 502,
+// 480: 513 / 507 - past n_cu the plain launch falls back to 512-thread workgroups and the tail help pays again until ~1.75
+// queries per CU. SGPU_COOP_MAX_NQ = n keeps the old rule "up to n".
+static bool coop_by_size(const DeviceIndex* d, uint32_t nq) {
+  const char* v = env_get("SGPU_COOP_MAX_NQ");
+  if (v && *v) return nq <= (uint32_t)std::strtoul(v, nullptr, 10);
+  return nq <= d->n_cu * 11u / 16u || (nq > d->n_cu && nq <= d->n_cu * 7u / 4u);
+}
+
 // Chooses block size, LDS layout and grid for one search pass (caller holds d->mu).
 static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sgpu_search_params& sp, uint32_t mode,
                              LaunchArgs* a) {
@@ -1134,7 +1146,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     const char* cm = env_get("SGPU_COOP");
     const bool force = cm && !std::strcmp(cm, "force");
     const bool off = (cm && !std::strcmp(cm, "0")) || d->coop_broken;
-    return !off && !want_counted && mode == MODE_SEARCH && (force || b->nq <= env_u32("SGPU_COOP_MAX_NQ", d->n_cu)) &&
+    return !off && !want_counted && mode == MODE_SEARCH && (force || coop_by_size(d, b->nq)) &&
            variant_built(NT, heap_variant(sp.k), false, true);
   }();
   const bool stream_wanted = !coop_wanted && !want_counted && mode == MODE_SEARCH && hook_u32("SGPU_STREAM", 1) &&
@@ -1273,8 +1285,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
     // (measured r03, 8.8M documents: 1 query 133 vs 200 us, 8: 147 vs 297, 64: 316 vs 412, 256: 431 vs 486;
     // from ~1000 queries per launch on the variant's own cost - 6 % slower rounds, idle workgroups kept
     // resident - outweighs what its tail help returns: 780 vs 742 us)
-    const uint32_t max_nq = env_u32("SGPU_COOP_MAX_NQ", d->n_cu);
-    if (!off && !a->counted && mode == MODE_SEARCH && a->lds_bytes - a->L.uni >= 4096 && (force || b->nq <= max_nq) &&
+    if (!off && !a->counted && mode == MODE_SEARCH && a->lds_bytes - a->L.uni >= 4096 && (force || coop_by_size(d, b->nq)) &&
         variant_built(NT, heap_variant(sp.k), false, true))   // (k > 256: the plain variant)
       a->coop.enabled = force ? 2u : 1u;
   }

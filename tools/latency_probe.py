@@ -35,7 +35,8 @@ def main():
     q_off, qc, qv = _native.synth(NQ, 30000, 43, 1, docs)
     env = {k: v for k, v in os.environ.items() if k.startswith("SGPU_")}
     out = {"n_docs": n, "env": env, "passes": {}}
-    for nq in (1, 8, 64, 256, 1000, 1250):
+    sizes = [int(x) for x in os.environ.get("LATENCY_PROBE_SIZES", "1,8,64,256,1000,1250").split(",")]
+    for nq in sizes:
         reps = 200 if nq == 1 else (20 if nq < 1000 else 4)
         batches = []
         for r in range(min(reps, NQ // nq)):
@@ -51,6 +52,8 @@ def main():
         out["passes"][nq] = {"wall_us": dt * 1e6, "kernel_us": km * 1e3 / len(batches), "us_per_query": dt * 1e6 / nq}
         print("nq=%4d: %.1f us wall per pass, %.1f us kernel, %.2f us/query" % (nq, dt * 1e6, km * 1e3 / len(batches), dt * 1e6 / nq))
         del batches
+    if os.environ.get("LATENCY_PROBE_SIZES"):
+        return
     nl = 200
     lo = q_off[:nl + 1]
     ix.search_sequential(lo[:11], qc, qv, 10, 4, 1.0, False)          # warm-up (grows the lane's arena)
