@@ -346,7 +346,7 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
     // (600 since r03: a 1250-query call - one rank's shard of a 10 000-query batch on eight GPUs - takes 1115 us in two
     // chunks against 1260 in one, a 2500-query call 1.94 against 2.35 ms: the host side of a chunk, ~0.3 us per query,
     // hides behind the previous chunk's kernel; chunks of ~300 lose to their launch tails. profiles/r03_chunk_probe.txt)
-    return v && *v ? (uint32_t)std::strtoul(v, nullptr, 10) : 600u;
+    return v && *v ? (uint32_t)std::strtoul(v, nullptr, 10) : 0xffffffffu;   // (unset: by the rule below; 0: never cut a call)
   }();
   struct Job {
     Lane* lane;
@@ -383,7 +383,10 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
     const char* th = std::getenv("SGPU_TEST_HOOKS");   // (a test hook: honoured only while SGPU_TEST_HOOKS=1 is set)
     const char* tv = (th && *th && *th != '0') ? std::getenv("SGPU_TAIL_COOP") : nullptr;
     const uint32_t want = tv && *tv ? (uint32_t)std::strtoul(tv, nullptr, 10) : 0u;
-    n_jobs = chunk_jobs(nq, chunk_min, chunk_max, want, want ? coop_auto_max_queries(d) : 0u, &tail);
+    // (r06: 1300 where the chunks are planned on the device - a 1250- or 2500-query call is then ONE launch: from two request
+    // threads 864 -> 781 us and 1551 -> 1475 us per call, from one thread no difference; profiles/r06_shard_probe_chunk_min.txt)
+    const uint32_t cmin = chunk_min != 0xffffffffu ? chunk_min : (device_plan_applies(d, params) ? 1300u : 600u);
+    n_jobs = chunk_jobs(nq, cmin, chunk_max, want, want ? coop_auto_max_queries(d) : 0u, &tail);
   }
   std::vector<uint64_t> off;   // a chunk's offsets, rebased (sized here: nothing below allocates host memory)
   if (n_jobs > 1) {
