@@ -1393,6 +1393,10 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   if (a->coop.enabled && b->nq <= d->n_cu && !hook_get("SGPU_ITEMS_INIT"))
     a->p.items_init = std::min<uint32_t>(a->p.items_max, std::max<uint32_t>(1, hook_u32("SGPU_COOP_ITEMS_INIT", 128)));
   if (!a->coop.enabled) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
+  if (!a->coop.enabled && b->staged && grid == d->n_cu * (uint32_t)per_cu) {   // (experiment: slots left free for the next chunk's plan kernels)
+    const uint32_t spare = hook_u32("SGPU_GRID_SPARE", 0);
+    if (spare && grid > 2 * spare) grid -= spare;
+  }
   a->grid = grid;
   // A cooperative launch that writes its rows straight into the pinned host arena also tells the host when the LAST
   // query's rows are there (BatchView::done): the call returns them while the launch winds down (helpers leaving, the
