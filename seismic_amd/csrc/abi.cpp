@@ -37,7 +37,8 @@ sgpu_status batch_fetch(DeviceIndex* d, Lane* lane, sgpu_batch* b, uint32_t k, f
                         uint32_t* out_n);
 sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out);
 sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
-                          const float* vals, uint32_t nq, uint32_t q_base, const sgpu_search_params& sp, sgpu_batch** slot);
+                          const float* vals, uint32_t nq, uint32_t q_base, const sgpu_search_params& sp, sgpu_batch** slot,
+                          bool followed);
 sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_scores, uint64_t* out_ids, uint32_t* out_n);
 sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list, const uint32_t* comps,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
@@ -437,7 +438,7 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
       qo = off.data();
     }
     st = staged_launch(d, jb.lane, dim, qo, comps ? comps + q_off[jb.q0] : nullptr, vals ? vals + q_off[jb.q0] : nullptr,
-                       jb.q1 - jb.q0, q_base + jb.q0, params, lane_scratch(jb.lane));
+                       jb.q1 - jb.q0, q_base + jb.q0, params, lane_scratch(jb.lane), j + 1 < n_jobs || in_flight.shared);
     if (st == SGPU_OK) ++launched;
     else msg = last_error();
   }

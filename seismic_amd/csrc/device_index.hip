@@ -598,6 +598,7 @@ struct sgpu_batch {
   uint32_t* queue_dev = nullptr;
   uint32_t device_plan_cut = 0xffffffffu;   // the chunk's launch plan was computed on the device for this query_cut (its
                                             //   maxima come back in words 1 - 3 of the status block); 0xffffffff: host plan
+  bool followed = false;                    // another chunk of the call comes after this one, or other calls are in flight
 };
 
 namespace sgpu {
@@ -1393,8 +1394,16 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   if (a->coop.enabled && b->nq <= d->n_cu && !hook_get("SGPU_ITEMS_INIT"))
     a->p.items_init = std::min<uint32_t>(a->p.items_max, std::max<uint32_t>(1, hook_u32("SGPU_COOP_ITEMS_INIT", 128)));
   if (!a->coop.enabled) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
-  if (!a->coop.enabled && b->staged && grid == d->n_cu * (uint32_t)per_cu) {   // (experiment: slots left free for the next chunk's plan kernels)
-    const uint32_t spare = hook_u32("SGPU_GRID_SPARE", 0);
+  // A chunk whose plan was computed on the device and that is followed by another (the next chunk of its call, or other
+  // request threads' calls) leaves kPlanSpareSlots of the chip's workgroup slots free - one per XCD. The search kernel's
+  // persistent workgroups fill every register of every CU until the first of them runs out of queries, and the plan
+  // kernels of the NEXT chunk would wait for that moment: the next search launch then starts when this one ends instead
+  // of filling its tail (profiles/r06_entry_timeline.txt). Workgroups go to the XCDs round-robin, so the plan kernels'
+  // blocks need room on EVERY XCD: two or four free slots changed nothing, eight: one request thread 1.63 -> 1.69 M
+  // queries/s, two threads 1.73 -> 1.79 M. Eight slots of 512 cost 1.6 % of that launch. SGPU_GRID_SPARE=n (a test
+  // hook) overrides.
+  if (!a->coop.enabled && b->staged && b->device_plan_cut != 0xffffffffu && grid == d->n_cu * (uint32_t)per_cu) {
+    const uint32_t spare = hook_get("SGPU_GRID_SPARE") ? hook_u32("SGPU_GRID_SPARE", 0) : (b->followed ? (uint32_t)kPlanSpareSlots : 0u);
     if (spare && grid > 2 * spare) grid -= spare;
   }
   a->grid = grid;
@@ -1593,15 +1602,22 @@ static inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 // D2H, all enqueued; staged_finish waits and hands the rows out. *slot is the lane's recycled batch.
 // (q_base: the index of the first query in the caller's batch, for error messages.)
 sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
-                          const float* vals, uint32_t nq, uint32_t q_base, const sgpu_search_params& sp, sgpu_batch** slot) {
+                          const float* vals, uint32_t nq, uint32_t q_base, const sgpu_search_params& sp, sgpu_batch** slot,
+                          bool followed) {
   if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
   if (sp.k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
   if (sp.k > 1024) return fail(SGPU_ELIMIT, "k = %u exceeds the heap limit of 1024", sp.k);
   uint32_t max_nnz = 0;
   PhaseClock pc;
   env_refresh();
-  sgpu_status st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz, q_base);
+  // The offsets first (sizes, max_nnz); the components of a chunk whose plan the host computes right away - make_plan
+  // indexes the index's arrays with them - and those of a device-planned chunk AFTER its H2D copy is enqueued: the pass
+  // over the components (~50 us per 5000 queries) then runs while the copy does, ahead of the plan kernels and the search.
+  if (!q_off || q_off[0] != 0) return fail(SGPU_EINVAL, "q_off[0] must be 0");
+  sgpu_status st = validate_query_offsets(q_off, nq, q_base, &max_nnz);
   if (st != SGPU_OK) return st;
+  if (q_off[nq] && (!comps || !vals)) return fail(SGPU_EINVAL, "null query arrays");
+  bool validated = false;
   HIP_TRY(hipSetDevice(d->device));
   const uint64_t nnz = q_off[nq];
   const uint32_t k = sp.k;
@@ -1652,6 +1668,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     b->status_off = o_status;
     return SGPU_OK;
   }
+  const uint32_t direct_max = hook_u32("SGPU_DIRECT_OUT_MAX", 16);   // (read per call: the knob cache is refreshed per call)
   const uint32_t qn = std::max<uint32_t>(4, (max_nnz + 3u) & ~3u);
   const uint32_t cut = std::min<uint32_t>(sp.query_cut, qn);
   try {
@@ -1666,6 +1683,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   // sort buffer must hold the chunk's largest first list: the host plan knows it exactly), for query_cut > 16 and for the
   // hashed lookup of u32 indexes (per-query seeds). SGPU_DEVICE_PLAN=0: always the host.
   b->device_plan_cut = 0xffffffffu;
+  b->followed = followed;
   {
     const bool hash_family = d->comp_width == 4 && d->value_type == SGPU_VAL_F16 && d->view.dim < (1u << 24);
     uint32_t seen = 0;
@@ -1674,6 +1692,12 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
       std::lock_guard<std::mutex> lock(d->mu);
       auto it = d->plan_dots_seen.find(cut);
       if (it != d->plan_dots_seen.end()) seen = it->second;
+    }
+    if (seen && nq <= direct_max) seen = 0;   // (a call that small never copies its queries down: kDevicePlanMinQueries is far above, this is for the knob)
+    if (!seen) {
+      st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz, q_base);
+      if (st != SGPU_OK) return st;
+      validated = true;
     }
     if (seen) {
       sgpu_batch_plan& pl = b->plans.back();
@@ -1710,7 +1734,6 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   // kernel READ its queries (a few hundred bytes) from that arena: no H2D copy to enqueue (5 us of host time and a
   // copy command ahead of the kernel) - which leaves the work counter: it is not zeroed per launch but runs on
   // (KParams::queue_base; Lane::queue_pos mirrors it on the host).
-  const uint32_t direct_max = hook_u32("SGPU_DIRECT_OUT_MAX", 16);   // (read per call: the knob cache is refreshed per call)
   const uint32_t direct_in_on = env_u32("SGPU_DIRECT_IN", 1);
   b->direct_out = b->arena_host_dev != nullptr && nq <= direct_max;
   b->direct_in = b->direct_out && direct_in_on != 0;
@@ -1739,6 +1762,16 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
     b->queue_base = lane->queue_pos;
   } else {
     HIP_TRY(hipMemcpyAsync(b->arena_dev, hs, in_bytes, hipMemcpyHostToDevice, lane->stream));
+    if (!validated) {   // (the copy is on its way: nothing that reads the components has been enqueued yet)
+      st = validate_queries(dim, q_off, comps, vals, nq, &max_nnz, q_base);
+      if (st != SGPU_OK) {
+        const std::string msg = last_error();
+        (void)hipStreamSynchronize(lane->stream);
+        last_error() = msg;
+        return st;
+      }
+      validated = true;
+    }
     if (b->device_plan_cut != 0xffffffffu) {
       // order -> the arena's order region; the maxima -> words 1 - 3 of the status block (zeroed by the copy above, they
       // come back with the rows); the sort keys borrow the output region, which the search kernel overwrites afterwards

@@ -254,5 +254,14 @@ def test_the_device_plans_a_chunk_as_the_host_does(monkeypatch):
     _same(ix.batch_search(*few, 10, 6, 0.9, False), orc.batch_search(ix.desc, *few, 10, 6, 0.9, False)[:3])
     for _ in range(3):   # (device plans from the second chunk on; the cache grows to what the chunks report)
         _same(ix.batch_search(*q, 10, 6, 0.9, False), exp)
+    # a device-planned chunk checks its components while its H2D copy is under way, before anything that reads them is
+    # enqueued: the errors are the host-planned chunk's, and the lane serves the next call
+    at = int(q_off[2500])
+    for what, (c2, v2) in {"component >= dim": (np.where(np.arange(len(qc)) == at, dim + 9, qc).astype(qc.dtype), qv),
+                           "NaN value": (qc, np.where(np.arange(len(qv)) == at, np.nan, qv).astype(qv.dtype))}.items():
+        with pytest.raises(_native.SeismicHipError) as e:
+            ix.batch_search(q_off, c2, v2, 10, 6, 0.9, False)
+        assert "query 2500" in str(e.value) and what in str(e.value), str(e.value)
+        _same(ix.batch_search(*q, 10, 6, 0.9, False), exp)
     monkeypatch.setenv("SGPU_DEVICE_PLAN", "0")
     _same(ix.batch_search(*q, 10, 6, 0.9, False), exp)
