@@ -323,24 +323,10 @@ static uint32_t chunk_jobs(uint32_t nq, uint32_t chunk_min, uint32_t chunk_max, 
   }
   return n_jobs;
 }
-static uint32_t chunk_first_permille() {   // (experiment: the first of two chunks takes this share of the call; 0 = equal chunks)
-  static const uint32_t pm = [] {
-    const char* v = std::getenv("SGPU_CHUNK_FIRST");
-    const uint32_t n = v && *v ? (uint32_t)std::strtoul(v, nullptr, 10) : 0u;
-    return n >= 1000 ? 0u : n;
-  }();
-  return pm;
-}
 static void chunk_bounds(uint32_t nq, uint32_t n_jobs, uint32_t tail, uint32_t j, uint32_t* q0, uint32_t* q1) {
   if (tail && n_jobs == 2) {
     *q0 = j == 0 ? 0 : nq - tail;
     *q1 = j == 0 ? nq - tail : nq;
-    return;
-  }
-  if (n_jobs == 2 && chunk_first_permille()) {
-    const uint32_t cut = std::max<uint32_t>(1, (uint32_t)((uint64_t)nq * chunk_first_permille() / 1000));
-    *q0 = j == 0 ? 0 : cut;
-    *q1 = j == 0 ? cut : nq;
     return;
   }
   *q0 = (uint32_t)((uint64_t)nq * j / n_jobs);
@@ -406,7 +392,7 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
   std::vector<uint64_t> off;   // a chunk's offsets, rebased (sized here: nothing below allocates host memory)
   if (n_jobs > 1) {
     try {
-      off.resize(chunk_first_permille() ? (size_t)nq + 2 : (size_t)nq / 2 + 2);
+      off.resize((size_t)nq / 2 + 2);
     } catch (const std::exception&) {
       n_jobs = 1;
     }
