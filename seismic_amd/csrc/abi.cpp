@@ -38,7 +38,7 @@ sgpu_status batch_fetch(DeviceIndex* d, Lane* lane, sgpu_batch* b, uint32_t k, f
 sgpu_status batch_fetch_stats(DeviceIndex* d, sgpu_batch* b, uint32_t* out);
 sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
                           const float* vals, uint32_t nq, uint32_t q_base, const sgpu_search_params& sp, sgpu_batch** slot,
-                          bool followed);
+                          uint32_t followed);   // (0: nothing behind this chunk; 1: other calls; 2: the call's own next chunk)
 sgpu_status staged_finish(DeviceIndex* d, Lane* lane, sgpu_batch* b, float* out_scores, uint64_t* out_ids, uint32_t* out_n);
 sgpu_status summary_distances(DeviceIndex* d, const HostIndex& h, uint32_t list, const uint32_t* comps,
                               const float* vals, uint32_t nnz, float* out_dots, uint32_t* out_nb);
@@ -424,7 +424,7 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
       qo = off.data();
     }
     st = staged_launch(d, jb.lane, dim, qo, comps ? comps + q_off[jb.q0] : nullptr, vals ? vals + q_off[jb.q0] : nullptr,
-                       jb.q1 - jb.q0, q_base + jb.q0, params, lane_scratch(jb.lane), j + 1 < n_jobs || in_flight.shared);
+                       jb.q1 - jb.q0, q_base + jb.q0, params, lane_scratch(jb.lane), j + 1 < n_jobs ? 2u : (in_flight.shared ? 1u : 0u));
     if (st == SGPU_OK) ++launched;
     else msg = last_error();
   }

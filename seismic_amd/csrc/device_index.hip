@@ -599,6 +599,7 @@ struct sgpu_batch {
   uint32_t device_plan_cut = 0xffffffffu;   // the chunk's launch plan was computed on the device for this query_cut (its
                                             //   maxima come back in words 1 - 3 of the status block); 0xffffffff: host plan
   bool followed = false;                    // another chunk of the call comes after this one, or other calls are in flight
+  bool plan_identity = false;               // a device-planned chunk that takes its queries in input order (staged_launch)
 };
 
 namespace sgpu {
@@ -1260,7 +1261,7 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   a->qb.out_n = b->out_n;
   a->qb.q_order = nullptr;
   a->qb.q_seed = nullptr;
-  if (pl && !hook_u32("SGPU_NO_LPT", 0) && b->nq) {
+  if (pl && !hook_u32("SGPU_NO_LPT", 0) && b->nq && !b->plan_identity) {
     // the processing order lives in the batch's own device buffer (no allocation on the path)
     if (b->order_cut != cut) {
       if (b->order_cut != 0xffffffffu) HIP_TRY(hipStreamSynchronize(lane->stream));   // the staging copy may be in flight
@@ -1603,7 +1604,7 @@ static inline size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 // (q_base: the index of the first query in the caller's batch, for error messages.)
 sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64_t* q_off, const uint32_t* comps,
                           const float* vals, uint32_t nq, uint32_t q_base, const sgpu_search_params& sp, sgpu_batch** slot,
-                          bool followed) {
+                          uint32_t followed) {
   if (!d) return fail(SGPU_EDEVICE, "index is not uploaded to a device (call sgpu_index_upload)");
   if (sp.k == 0) return fail(SGPU_EINVAL, "k must be > 0 (KHeap::new asserts, reference src/utils.rs:23)");
   if (sp.k > 1024) return fail(SGPU_ELIMIT, "k = %u exceeds the heap limit of 1024", sp.k);
@@ -1683,7 +1684,8 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
   // sort buffer must hold the chunk's largest first list: the host plan knows it exactly), for query_cut > 16 and for the
   // hashed lookup of u32 indexes (per-query seeds). SGPU_DEVICE_PLAN=0: always the host.
   b->device_plan_cut = 0xffffffffu;
-  b->followed = followed;
+  b->followed = followed != 0;
+  b->plan_identity = false;
   {
     const bool hash_family = d->comp_width == 4 && d->value_type == SGPU_VAL_F16 && d->view.dim < (1u << 24);
     uint32_t seen = 0;
@@ -1708,6 +1710,11 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
       pl.hash_ok = false;
       pl.order.clear();
       b->device_plan_cut = cut;
+      // The chunk's own call sends another chunk right behind it: the order in which this one takes its queries decides
+      // how long ITS tail is, and the next chunk's workgroups fill that tail whatever its length - the plan kernels (56 us
+      // ahead of the first search workgroup of a call) are skipped, the queries are taken in input order (q_order = null),
+      // and the LDS need of the index keeps coming from the chunks that are planned (SGPU_PLAN_IDENTITY=0, a test hook).
+      b->plan_identity = followed == 2 && hook_u32("SGPU_PLAN_IDENTITY", 1) != 0;
     } else {
       st = make_plan(d, q_off, comps, vals, nq, cut, &b->plans.back());
       if (st != SGPU_OK) return st;
@@ -1772,7 +1779,7 @@ sgpu_status staged_launch(DeviceIndex* d, Lane* lane, uint64_t dim, const uint64
       }
       validated = true;
     }
-    if (b->device_plan_cut != 0xffffffffu) {
+    if (b->device_plan_cut != 0xffffffffu && !b->plan_identity) {
       // order -> the arena's order region; the maxima -> words 1 - 3 of the status block (zeroed by the copy above, they
       // come back with the rows); the sort keys borrow the output region, which the search kernel overwrites afterwards
       // (16 bytes per query at least: room for the <= 2 nq keys)
