@@ -323,10 +323,15 @@ static uint32_t chunk_jobs(uint32_t nq, uint32_t chunk_min, uint32_t chunk_max, 
   }
   return n_jobs;
 }
-static void chunk_bounds(uint32_t nq, uint32_t n_jobs, uint32_t tail, uint32_t j, uint32_t* q0, uint32_t* q1) {
+static void chunk_bounds(uint32_t nq, uint32_t n_jobs, uint32_t tail, uint32_t j, uint32_t* q0, uint32_t* q1, uint32_t first = 0) {
   if (tail && n_jobs == 2) {
     *q0 = j == 0 ? 0 : nq - tail;
     *q1 = j == 0 ? nq - tail : nq;
+    return;
+  }
+  if (first && n_jobs == 2 && first < nq) {   // (two chunks, the first one of `first` queries)
+    *q0 = j == 0 ? 0 : first;
+    *q1 = j == 0 ? first : nq;
     return;
   }
   *q0 = (uint32_t)((uint64_t)nq * j / n_jobs);
@@ -389,10 +394,18 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
     const uint32_t cmin = chunk_min != 0xffffffffu ? chunk_min : (device_plan_applies(d, params) ? 1300u : 600u);
     n_jobs = chunk_jobs(nq, cmin, chunk_max, want, want ? coop_auto_max_queries(d) : 0u, &tail);
   }
+  // (experiment, a test hook: SGPU_CHUNK_FIRST = share of the call, in per mille, that the first of two chunks takes)
+  uint32_t first = 0;
+  if (n_jobs == 2 && !tail) {
+    const char* th = std::getenv("SGPU_TEST_HOOKS");
+    const char* fv = (th && *th && *th != '0') ? std::getenv("SGPU_CHUNK_FIRST") : nullptr;
+    const uint32_t pm = fv && *fv ? (uint32_t)std::strtoul(fv, nullptr, 10) : 0u;
+    if (pm > 0 && pm < 1000) first = std::max<uint32_t>(1, (uint32_t)((uint64_t)nq * pm / 1000));
+  }
   std::vector<uint64_t> off;   // a chunk's offsets, rebased (sized here: nothing below allocates host memory)
   if (n_jobs > 1) {
     try {
-      off.resize((size_t)nq / 2 + 2);
+      off.resize(first ? (size_t)nq + 2 : (size_t)nq / 2 + 2);
     } catch (const std::exception&) {
       n_jobs = 1;
     }
@@ -417,7 +430,7 @@ static sgpu_status search_shard(DeviceIndex* d, uint64_t dim, const uint64_t* q_
   }
   for (uint32_t j = 0; j < n_jobs && st == SGPU_OK; ++j) {
     Job& jb = jobs[j];
-    chunk_bounds(nq, n_jobs, tail, j, &jb.q0, &jb.q1);
+    chunk_bounds(nq, n_jobs, tail, j, &jb.q0, &jb.q1, first);
     const uint64_t* qo = q_off;
     if (n_jobs > 1 && jb.q0 != 0) {   // (a chunk that starts at query 0 uses the caller's offsets as they are)
       for (uint32_t q = jb.q0; q <= jb.q1; ++q) off[q - jb.q0] = q_off[q] - q_off[jb.q0];
