@@ -198,7 +198,7 @@ struct LaunchArgs {
 
 hipError_t launch_search(const LaunchArgs& a);
 // plan_kernel.hip: the launch plan of a staged chunk computed on the device (order + the maxima the LDS layout wants)
-enum { kDevicePlanMaxQueries = 16384, kDevicePlanMinQueries = 256, kDevicePlanCutMax = 16, kPlanSpareSlots = 8 };
+enum { kDevicePlanMaxQueries = 16384, kDevicePlanMinQueries = 256, kDevicePlanCutMax = 16, kCusPerXcd = 32 };
 hipError_t launch_device_plan(const DevView& ix, const uint32_t* q_off, const uint32_t* q_comp, const float* q_val, uint32_t nq,
                               uint32_t cut, uint64_t* keys_scratch, uint32_t* maxima, uint32_t* order, hipStream_t stream);
 

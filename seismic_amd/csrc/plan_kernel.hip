@@ -16,7 +16,7 @@
 //                      workgroup, its four wavefronts count over a quarter of the keys each (a tile of 64 keys sits
 //                      in one register pair across the lanes and is read back lane by lane).
 // Both are grids of 256-thread workgroups without LDS to speak of: the plan of chunk i + 1 runs in the slots the search
-// kernel of chunk i leaves free (device_index.hip: kPlanSpareSlots) instead of waiting for its tail. The first version
+// kernel of chunk i leaves free (device_index.hip, configure: one slot per XCD) instead of waiting for its tail. The first version
 // (one 1024-thread workgroup sorting bitonically in 64 KB of LDS, three same-address atomics per query) took 210 us per
 // 5000-query chunk on an empty chip and could not become resident beside a search launch at all: the next chunk's
 // search started when the previous one ended (profiles/r06_entry_timeline.txt).
