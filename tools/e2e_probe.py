@@ -13,13 +13,14 @@ else:
     from seismic_amd._abi import BuildConfig
     ix=_native.NativeIndex.build(2,30000,*docs,BuildConfig.defaults(n_postings=2000,centroid_fraction=0.2,summary_energy=0.5,max_fraction=6.0,use_device=1)); ix.save(path)
 ix.upload(0)
-q_off,qc,qv=_native.synth(60000,30000,43,1,docs)
+NB=int(os.environ.get('E2E_BATCHES','6'))   # (24: the batches are cold in the host's caches, as in the bench line's leg)
+q_off,qc,qv=_native.synth(10000*NB,30000,43,1,docs)
 hb=[]
-for r in range(6):
+for r in range(NB):
     lo,hi=r*10000,(r+1)*10000
     hb.append(((q_off[lo:hi+1]-q_off[lo]).astype(np.uint64), qc[q_off[lo]:q_off[hi]], qv[q_off[lo]:q_off[hi]]))
-outs=[(np.zeros((10000,10),np.float32),np.zeros((10000,10),np.uint64),np.zeros(10000,np.uint32)) for _ in range(6)]
-def call(i): ix.batch_search(*hb[i%6],10,4,1.0,False,out=outs[i%6])
+outs=[(np.zeros((10000,10),np.float32),np.zeros((10000,10),np.uint64),np.zeros(10000,np.uint32)) for _ in range(NB)]
+def call(i): ix.batch_search(*hb[i%NB],10,4,1.0,False,out=outs[i%NB])
 for nt in (1,2):
     for i in range(4): call(i)
     K=24
