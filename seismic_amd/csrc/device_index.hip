@@ -1395,16 +1395,14 @@ static sgpu_status configure(DeviceIndex* d, Lane* lane, sgpu_batch* b, const sg
   if (a->coop.enabled && b->nq <= d->n_cu && !hook_get("SGPU_ITEMS_INIT"))
     a->p.items_init = std::min<uint32_t>(a->p.items_max, std::max<uint32_t>(1, hook_u32("SGPU_COOP_ITEMS_INIT", 128)));
   if (!a->coop.enabled) grid = std::max<uint32_t>(1, std::min<uint32_t>(grid, b->nq));
-  // A chunk whose plan was computed on the device and that is followed by another (the next chunk of its call, or other
-  // request threads' calls) leaves n_cu / 32 of the chip's workgroup slots free - one per XCD. The search kernel's
-  // persistent workgroups fill every register of every CU until the first of them runs out of queries, and the plan
-  // kernels of the NEXT chunk would wait for that moment: the next search launch then starts when this one ends instead
-  // of filling its tail (profiles/r06_entry_timeline.txt). Workgroups go to the XCDs round-robin, so the plan kernels'
-  // blocks need room on EVERY XCD: two or four free slots changed nothing, eight: one request thread 1.63 -> 1.69 M
-  // queries/s, two threads 1.73 -> 1.79 M. Eight slots of 512 cost 1.6 % of that launch. SGPU_GRID_SPARE=n (a test
-  // hook) overrides.
+  // SGPU_GRID_SPARE=n (a test hook): a device-planned chunk launches n workgroups fewer than the chip holds. The idea - the
+  // plan kernels of the NEXT chunk run in the free slots instead of waiting for this launch's tail - did not survive its
+  // measurements (profiles/r06_entry_point_final.txt): with one free slot per XCD the next chunk's plan still completes
+  // only when this launch's workgroups start to leave (events on the two streams, no profiler attached); with 32 and more
+  // it completes at once, but the next search launch then shares the chip with this one from the start and the call
+  // gets slower (6.15 against 5.95 ms). No slots are left free by default.
   if (!a->coop.enabled && b->staged && b->device_plan_cut != 0xffffffffu && grid == d->n_cu * (uint32_t)per_cu) {
-    const uint32_t spare = hook_get("SGPU_GRID_SPARE") ? hook_u32("SGPU_GRID_SPARE", 0) : (b->followed ? std::max<uint32_t>(1, d->n_cu / kCusPerXcd) : 0u);   // (one per XCD: 8 on an unpartitioned MI355X)
+    const uint32_t spare = hook_u32("SGPU_GRID_SPARE", 0);
     if (spare && grid > 2 * spare) grid -= spare;
   }
   a->grid = grid;

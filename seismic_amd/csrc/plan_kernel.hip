@@ -15,11 +15,11 @@
 //                      distinct (the query is their low half), so a rank is a count of smaller keys: 64 queries per
 //                      workgroup, its four wavefronts count over a quarter of the keys each (a tile of 64 keys sits
 //                      in one register pair across the lanes and is read back lane by lane).
-// Both are grids of 256-thread workgroups without LDS to speak of: the plan of chunk i + 1 runs in the slots the search
-// kernel of chunk i leaves free (device_index.hip, configure: one slot per XCD) instead of waiting for its tail. The first version
-// (one 1024-thread workgroup sorting bitonically in 64 KB of LDS, three same-address atomics per query) took 210 us per
-// 5000-query chunk on an empty chip and could not become resident beside a search launch at all: the next chunk's
-// search started when the previous one ended (profiles/r06_entry_timeline.txt).
+// Both are grids of 256-thread workgroups without LDS to speak of. The first version (one 1024-thread workgroup sorting
+// bitonically in 64 KB of LDS, three same-address atomics per query) took 205 us per 5000-query chunk on an empty chip
+// (profiles/r06_entry_timeline.txt); these take 56. Beside a resident search launch - whose persistent workgroups hold
+// every register of every CU - neither version runs before that launch's first workgroups leave: the next chunk's search
+// starts in this one's tail (profiles/r06_entry_point_final.txt).
 // The LDS layout itself is sized on the host from the maxima of EARLIER chunks on the same index and query_cut (they
 // travel back with the rows); a query that needs more block dots than that walks its lists in groups - slower for that
 // query, identical results (search_kernel.inc: plan_list_group).

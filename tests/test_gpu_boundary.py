@@ -263,9 +263,9 @@ def test_the_device_plans_a_chunk_as_the_host_does(monkeypatch):
             ix.batch_search(q_off, c2, v2, 10, 6, 0.9, False)
         assert "query 2500" in str(e.value) and what in str(e.value), str(e.value)
         _same(ix.batch_search(*q, 10, 6, 0.9, False), exp)
-    # the first of a call's two chunks is not planned (input order) and leaves one workgroup slot per XCD free for the
-    # second chunk's plan kernels: planned after all, with no free slots, with more of them - the oracle's rows
-    for env in ({"SGPU_PLAN_IDENTITY": "0"}, {"SGPU_GRID_SPARE": "0"}, {"SGPU_GRID_SPARE": "24", "SGPU_PLAN_IDENTITY": "0"}):
+    # the first of a call's two chunks is not planned (input order): planned after all, and launches that leave workgroup
+    # slots free (SGPU_GRID_SPARE, an experiment that was withdrawn) - the oracle's rows
+    for env in ({"SGPU_PLAN_IDENTITY": "0"}, {"SGPU_GRID_SPARE": "8"}, {"SGPU_GRID_SPARE": "24", "SGPU_PLAN_IDENTITY": "0"}):
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
         _same(ix.batch_search(*q, 10, 6, 0.9, False), exp)
